@@ -1,0 +1,286 @@
+/*
+ * rtk.h -- C ABI of the MI355X path-tracing kernel library (librtk_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of the reference: the per-pixel
+ * sample loop behind camera::render() (Camera.txt:54-119 -> get_ray :177-191 ->
+ * ray_color :203-238 -> hittable::hit / material::scatter / texture::value).
+ * The reference has no FFI of its own; the only boundary it
+ * offers is the header-level C++ scene API that main.cpp programs against.
+ * The build keeps that API (raytracingoneweekendapplication_amd/host/) and its
+ * camera::render() calls the functions below instead of spawning std::async
+ * row workers (Camera.txt:59-61,96-100).
+ *
+ * Conventions
+ *   - plain C, no torch / C++ types; every function returns 0 on success or a
+ *     negative rtk_status; rtk_last_error() gives the text of the last failure
+ *     on the calling thread.  Nothing throws across the boundary.
+ *   - the caller owns every host buffer it passes; rtk_ctx owns device memory.
+ *   - "device pointer" arguments are raw HIP device addresses (e.g. a torch
+ *     tensor's data_ptr()); "stream" is a hipStream_t passed as void* (NULL =
+ *     the default stream).
+ *   - all scene reals are IEEE double, exactly the values the reference's
+ *     constructors compute (vec3.h:7 `double e[3]`); rtk_scene_upload converts
+ *     to float for the RTK_REAL_F32 kernels.
+ *   - there is no CPU fallback: every entry point that computes fails with
+ *     RTK_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef RTK_H
+#define RTK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTK_ABI_VERSION 1
+
+typedef enum rtk_status {
+    RTK_OK = 0,
+    RTK_ERR_INVALID = -1,      /* bad argument / malformed scene description     */
+    RTK_ERR_NO_DEVICE = -2,    /* no usable HIP device (product never falls back) */
+    RTK_ERR_HIP = -3,          /* a HIP runtime call failed                       */
+    RTK_ERR_UNSUPPORTED = -4,  /* scene uses a construct the kernel does not run  */
+    RTK_ERR_NO_SCENE = -5      /* render requested before rtk_scene_upload        */
+} rtk_status;
+
+typedef struct rtk_vec3 { double x, y, z; } rtk_vec3;
+
+/* ------------------------------------------------------------------------
+ * Scene description: an index-based copy of the reference's pointer graph.
+ * One rtk_node per `hittable` object (hittable.h:29-36); shared_ptr edges
+ * become node indices, so a DAG (e.g. the fog boundary that is also in the
+ * world, main.cpp:305-307) stays a DAG.
+ * ---------------------------------------------------------------------- */
+typedef enum rtk_node_kind {
+    RTK_NODE_SPHERE = 1,     /* sphere.h:12-28        a = index into spheres[]          */
+    RTK_NODE_QUAD = 2,       /* quad.h:10-19          a = index into quads[]            */
+    RTK_NODE_TRIANGLE = 3,   /* triangle.h:17-45      a = index into triangles[]        */
+    RTK_NODE_LIST = 4,       /* hittable_list.h:9-41  a = first slot in list_children[], b = count */
+    RTK_NODE_BVH = 5,        /* bvh.h:11-79           a = left node, b = right node, c = index into bvh_boxes[] */
+    RTK_NODE_TRANSLATE = 6,  /* hittable.h:39-65      a = index into translates[], b = child node */
+    RTK_NODE_ROTATE_Y = 7,   /* hittable.h:67-146     a = index into rotates[],    b = child node */
+    RTK_NODE_MEDIUM = 8      /* constant_medium.h:8-60 a = index into media[],     b = boundary node */
+} rtk_node_kind;
+
+typedef struct rtk_node { int32_t kind, a, b, c; } rtk_node;
+
+/* sphere.h:60-64: `ray center` (origin = center1, direction = center2-center1),
+ * radius = fmax(0, r).  A stationary sphere has center_dir = 0. */
+typedef struct rtk_sphere {
+    rtk_vec3 center0, center_dir;
+    double radius;
+    int32_t material, _pad;
+} rtk_sphere;
+
+/* quad.h:76-83: Q, u, v, w = n/dot(n,n), normal = unit(n), D = dot(normal,Q). */
+typedef struct rtk_quad {
+    rtk_vec3 Q, u, v, w, normal;
+    double D;
+    int32_t material, _pad;
+} rtk_quad;
+
+/* triangle.h:124-143: vertices, unit normal, raw (un-wrapped) float UVs. */
+typedef struct rtk_triangle {
+    rtk_vec3 p0, p1, p2, normal;
+    float uv0[2], uv1[2], uv2[2];
+    int32_t material, _pad;
+} rtk_triangle;
+
+typedef struct rtk_aabb { double xmin, xmax, ymin, ymax, zmin, zmax; } rtk_aabb; /* aabb.h:12 */
+typedef struct rtk_translate { rtk_vec3 offset; } rtk_translate;                /* hittable.h:62 */
+typedef struct rtk_rotate_y { double sin_theta, cos_theta; } rtk_rotate_y;      /* hittable.h:142-143 */
+typedef struct rtk_medium {                                                     /* constant_medium.h:57-59 */
+    double neg_inv_density;
+    int32_t material, _pad;  /* the isotropic phase function */
+} rtk_medium;
+
+typedef enum rtk_material_kind {
+    RTK_MAT_LAMBERTIAN = 1,    /* material.h:22-41   tex                       */
+    RTK_MAT_METAL = 2,         /* material.h:78-92   albedo, param = fuzz (<=1) */
+    RTK_MAT_DIELECTRIC = 3,    /* material.h:43-76   param = refraction index  */
+    RTK_MAT_DIFFUSE_LIGHT = 4, /* material.h:94-122  tex (emissive_light is the same behaviour) */
+    RTK_MAT_ISOTROPIC = 5,     /* material.h:124-138 tex                       */
+    RTK_MAT_SPECULAR = 6       /* material.h:140-172 albedo, param = shininess */
+} rtk_material_kind;
+
+typedef struct rtk_material {
+    int32_t kind, texture;     /* texture = -1 when the material has none */
+    rtk_vec3 albedo;
+    double param;
+} rtk_material;
+
+typedef enum rtk_texture_kind {
+    RTK_TEX_SOLID = 1,         /* texture.h:20-32   color                                    */
+    RTK_TEX_CHECKER = 2,       /* texture.h:34-56   param = inv_scale, even/odd = texture ids */
+    RTK_TEX_CHECKER_TRI = 3,   /* texture.h:58-84   param = inv_scale, even/odd              */
+    RTK_TEX_IMAGE = 4,         /* texture.h:86-108  image = index into images[]              */
+    RTK_TEX_NOISE = 5          /* texture.h:110-120 param = scale, image = index into perlins[] */
+} rtk_texture_kind;
+
+typedef struct rtk_texture {
+    int32_t kind, even, odd, image;
+    rtk_vec3 color;
+    double param;
+} rtk_texture;
+
+/* rtw_stb_image.h:71-81: 8-bit RGB, row-major, 3 bytes per texel.  width == 0
+ * means "no data": image_texture::value returns cyan (texture.h:92). */
+typedef struct rtk_image {
+    int32_t width, height;
+    int64_t texel_offset;      /* byte offset of texel (0,0) in rtk_scene_desc.texels */
+} rtk_image;
+
+/* perlin.h:52-57: gradient table and the three permutation tables.  They are
+ * INPUTS to the device: the reference fills them from its global RNG at
+ * construction (perlin.h:6-13), which is host-side scene setup. */
+typedef struct rtk_perlin {
+    double randvec[256][3];
+    int32_t perm_x[256], perm_y[256], perm_z[256];
+} rtk_perlin;
+
+typedef struct rtk_point_light { rtk_vec3 position, intensity; double size; } rtk_point_light; /* point_light.h:24-27 */
+
+typedef struct rtk_scene_desc {
+    int32_t abi_version;       /* RTK_ABI_VERSION */
+    int32_t root;              /* node index `camera::render` is handed as `world` */
+    int32_t n_nodes, n_list_children, n_spheres, n_quads, n_triangles, n_bvh_boxes;
+    int32_t n_translates, n_rotates, n_media, n_materials, n_textures, n_images, n_perlins, n_lights;
+    int64_t n_texel_bytes;
+    const rtk_node* nodes;
+    const int32_t* list_children;
+    const rtk_sphere* spheres;
+    const rtk_quad* quads;
+    const rtk_triangle* triangles;
+    const rtk_aabb* bvh_boxes;
+    const rtk_translate* translates;
+    const rtk_rotate_y* rotates;
+    const rtk_medium* media;
+    const rtk_material* materials;
+    const rtk_texture* textures;
+    const rtk_image* images;
+    const uint8_t* texels;
+    const rtk_perlin* perlins;
+    const rtk_point_light* lights;  /* the `lights` argument of camera::render (Camera.txt:54) */
+} rtk_scene_desc;
+
+/* ------------------------------------------------------------------------
+ * Camera: the values camera::initialize() derives (Camera.txt:136-175).  The
+ * host computes them in double exactly as the reference does (tan/sin/cos stay
+ * on the host); the kernel only consumes them in get_ray (Camera.txt:177-200).
+ * ---------------------------------------------------------------------- */
+typedef struct rtk_camera {
+    int32_t image_width, image_height;   /* Camera.txt:39,137-138 */
+    int32_t samples_per_pixel, max_depth; /* Camera.txt:42-43     */
+    rtk_vec3 background;                  /* Camera.txt:44        */
+    rtk_vec3 center, pixel00_loc, pixel_delta_u, pixel_delta_v; /* Camera.txt:125-128 */
+    rtk_vec3 defocus_disk_u, defocus_disk_v;                    /* Camera.txt:130-131 */
+    double defocus_angle;                 /* Camera.txt:51        */
+    double pixel_samples_scale;           /* Camera.txt:124,140   */
+} rtk_camera;
+
+typedef enum rtk_real_mode {
+    RTK_REAL_F64 = 0,   /* the reference's arithmetic type; the parity mode        */
+    RTK_REAL_F32 = 1    /* throughput mode; parity is statistical only */
+} rtk_real_mode;
+
+/* Image tiles: one 8x8-pixel tile per 64-lane wavefront.  Tile t (row-major
+ * over ceil(W/8) x ceil(H/8)) belongs to rank (t % n_ranks) and is that rank's
+ * local tile (t / n_ranks).  n_ranks = 1 renders the whole image. */
+#define RTK_TILE_W 8
+#define RTK_TILE_H 8
+#define RTK_TILE_PIXELS 64
+
+typedef struct rtk_render_opts {
+    uint32_t seed;          /* render seed; per-sample stream = f(seed, pixel, sample) */
+    int32_t real_mode;      /* rtk_real_mode */
+    int32_t rank, n_ranks;  /* tile ownership; (0,1) = whole image */
+    int32_t count_work;     /* != 0: also accumulate rtk_work_counters (slower; not for timing) */
+    int32_t variant;        /* kernel variant selector, 0 = default */
+    void* stream;           /* hipStream_t, NULL = default stream */
+} rtk_render_opts;
+
+/* Exact per-render work counters (sums over all samples this rank traced);
+ * the "algorithmic bytes" model of SURVEY.md 8(d) is a linear form in them. */
+typedef struct rtk_work_counters {
+    uint64_t samples;        /* primary samples traced                         */
+    uint64_t segments;       /* ray segments = world.hit calls (Camera.txt:211) */
+    uint64_t box_tests;      /* aabb::hit calls (bvh.h:65)                V    */
+    uint64_t sphere_tests;   /* sphere::hit calls                        T_sphere */
+    uint64_t quad_tests;     /* quad::hit calls                          T_quad */
+    uint64_t triangle_tests; /* triangle::hit calls                      T_tri */
+    uint64_t xform_enters;   /* translate::hit + rotate_y::hit calls     X     */
+    uint64_t medium_tests;   /* constant_medium::hit calls               M     */
+    uint64_t surface_hits;   /* material interactions (Camera.txt:216-223) H   */
+    uint64_t noise_calls;    /* perlin::noise calls (perlin.h:14)        P     */
+    uint64_t texel_fetches;  /* rtw_image::pixel_data calls              I     */
+    uint64_t rng_draws;      /* random_double() calls (rtweekend.h:26)         */
+} rtk_work_counters;
+
+typedef struct rtk_ctx rtk_ctx;
+
+/* Version / diagnostics --------------------------------------------------- */
+int rtk_abi_version(void);
+const char* rtk_last_error(void);
+
+/* Lifetime ---------------------------------------------------------------- */
+/* Binds a context to HIP device `device` (ordinal as seen by this process). */
+int rtk_init(int device, rtk_ctx** out_ctx);
+int rtk_destroy(rtk_ctx* ctx);
+
+/* Scene --------------------------------------------------------------------
+ * Validates the description (>= 1 primitive reachable from root -- the
+ * reference recurses forever on an empty world, bvh.h:38-43 / SURVEY Q6),
+ * linearises the graph into the kernel's traversal program in the
+ * reference's visiting order (bvh.h:64-72: left, then right, both always)
+ * and uploads f64 and f32 copies.  Replaces any previously uploaded scene. */
+int rtk_scene_upload(rtk_ctx* ctx, const rtk_scene_desc* scene);
+
+/* Number of tiles rank `rank` of `n_ranks` owns for a W x H image, and the
+ * element count of its compact tile buffer (tiles * 3 * 64 reals). */
+int64_t rtk_tiles_per_rank(int image_width, int image_height, int n_ranks);
+
+/* Render -------------------------------------------------------------------
+ * The replacement for the body of camera::render (Camera.txt:65-93), device
+ * resident and asynchronous on opts->stream.
+ *   n_ranks == 1:  d_linear = row-major H*W*3 reals (double for F64, float for
+ *                  F32), the pixel colour AFTER the 1/spp scale and BEFORE
+ *                  gamma (Camera.txt:74); d_rgb8 = row-major H*W*3 bytes as
+ *                  Camera.txt:77-89 writes them.  Either may be NULL.
+ *   n_ranks  > 1:  d_linear = this rank's compact tile buffer
+ *                  [tiles_per_rank][3][64] reals; d_rgb8 must be NULL (bytes
+ *                  are produced by rtk_tiles_unpermute on the gathering rank).
+ * d_counters (device, sizeof(rtk_work_counters), zeroed by the caller) is
+ * required iff opts->count_work != 0. */
+int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts* opts,
+                      void* d_linear, uint8_t* d_rgb8, rtk_work_counters* d_counters);
+
+/* After gathering every rank's compact buffer into
+ * d_gathered[n_ranks][tiles_per_rank][3][64] (rank-major, as ncclGather /
+ * torch.distributed.gather lays them out): scatter to the row-major image
+ * and apply gamma/clamp/quantise.  Asynchronous on `stream`. */
+int rtk_tiles_unpermute(rtk_ctx* ctx, int image_width, int image_height, int n_ranks,
+                        int real_mode, const void* d_gathered,
+                        void* d_linear, uint8_t* d_rgb8, void* stream);
+
+/* Convenience for host callers (camera::render): allocates device buffers,
+ * renders the whole image, synchronises and copies back.  h_linear is
+ * H*W*3 doubles (F32 results are widened), h_rgb8 is H*W*3 bytes; either may
+ * be NULL.  counters may be NULL. */
+int rtk_render_host(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts* opts,
+                    double* h_linear, uint8_t* h_rgb8, rtk_work_counters* counters);
+
+/* Introspection of the uploaded scene's traversal program (for tests and
+ * for the byte model): number of program records and device bytes per mode. */
+int rtk_scene_info(rtk_ctx* ctx, int32_t* n_program_ops, int64_t* bytes_f64, int64_t* bytes_f32);
+
+/* Names of the kernel symbols rtk_render_device launches for (real_mode,
+ * variant) on the uploaded scene -- used to find the dispatch in rocprofv3
+ * traces.  Returns a static string. */
+const char* rtk_kernel_name(rtk_ctx* ctx, int real_mode, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTK_H */

@@ -1,0 +1,291 @@
+"""MI355X-native path tracer: Python plumbing over the C ABI of include/rtk.h.
+
+The product is ``librtk_hip.so`` (hand-written HIP for gfx950, csrc/) driven through
+the C ABI; this module only loads it with ctypes, mirrors the ABI structs and wraps
+handles in small classes so that tests and ``bench.py`` can pass torch device
+pointers and streams.  Scenes come from ``librtk_host.so`` -- the reference's scene
+API re-implemented in C++ (host/), which flattens a ``hittable`` graph into the
+``rtk_scene_desc`` the ABI takes.
+
+There is no CPU rendering path here.  If ``librtk_hip.so`` is missing or no gfx950
+device is usable, ``Renderer`` raises; nothing falls back to the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_PKG_DIR)
+HIP_LIB_PATH = os.path.join(_PKG_DIR, "librtk_hip.so")
+HOST_LIB_PATH = os.path.join(_PKG_DIR, "librtk_host.so")
+
+RTK_ABI_VERSION = 1
+RTK_REAL_F64 = 0
+RTK_REAL_F32 = 1
+TILE_PIXELS = 64
+
+SCENE_SEED = 0x5EED2025  # construction RNG seed of the BASELINE scenes
+RENDER_SEED = 1
+
+# BASELINE.json configs -> scene_library.h names
+CONFIG_SCENES = {
+    "c1": "three_spheres",
+    "c2": "book1_final",
+    "c3": "cornell_box",
+    "c4": "mesh",
+    "c5": "book2_final",
+}
+
+
+class RtkError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"rtk error {code}: {message}")
+        self.code = code
+
+
+# ----------------------------------------------------------------------------- ABI structs
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("z", C.c_double)]
+
+
+class Camera(C.Structure):
+    """rtk_camera (include/rtk.h): the values camera::initialize() derives."""
+
+    _fields_ = [
+        ("image_width", C.c_int32), ("image_height", C.c_int32),
+        ("samples_per_pixel", C.c_int32), ("max_depth", C.c_int32),
+        ("background", Vec3), ("center", Vec3), ("pixel00_loc", Vec3),
+        ("pixel_delta_u", Vec3), ("pixel_delta_v", Vec3),
+        ("defocus_disk_u", Vec3), ("defocus_disk_v", Vec3),
+        ("defocus_angle", C.c_double), ("pixel_samples_scale", C.c_double),
+    ]
+
+
+class RenderOpts(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint32), ("real_mode", C.c_int32), ("rank", C.c_int32), ("n_ranks", C.c_int32),
+        ("count_work", C.c_int32), ("variant", C.c_int32), ("stream", C.c_void_p),
+    ]
+
+
+COUNTER_FIELDS = (
+    "samples", "segments", "box_tests", "sphere_tests", "quad_tests", "triangle_tests",
+    "xform_enters", "medium_tests", "surface_hits", "noise_calls", "texel_fetches", "rng_draws",
+)
+
+
+class WorkCounters(C.Structure):
+    _fields_ = [(name, C.c_uint64) for name in COUNTER_FIELDS]
+
+    def as_dict(self) -> dict:
+        return {name: int(getattr(self, name)) for name in COUNTER_FIELDS}
+
+
+def algorithmic_bytes_per_sample(counters: dict, spp: int, real_mode: int) -> float:
+    """SURVEY.md 8(d) byte model: bytes the sample loop must touch per sample.
+
+    fp32 record sizes: BVH node 32, sphere 32, quad 68, triangle 76, instance
+    transform 24, medium 12, material 32, perlin::noise 120, texel 4, framebuffer
+    12 B/pixel.  In f64 mode the real-valued fields double (the 4-byte indices and
+    the u8 texel do not).
+    """
+    n = max(1, counters["samples"])
+    f64 = real_mode == RTK_REAL_F64
+    node = 56 if f64 else 32        # 6 reals + 2 u32
+    sphere = 60 if f64 else 32      # 7 reals + material
+    quad = 132 if f64 else 68       # 16 reals + material
+    tri = 124 if f64 else 76        # 12 reals + 6 float uv + material
+    xform = 44 if f64 else 24       # 5 reals + child
+    medium = 16 if f64 else 12
+    material = 48 if f64 else 32
+    noise = 216 if f64 else 120     # 8 gradients of 3 reals + 6 perm ints
+    fb = 24 if f64 else 12
+    total = (node * counters["box_tests"] + sphere * counters["sphere_tests"] + quad * counters["quad_tests"]
+             + tri * counters["triangle_tests"] + xform * counters["xform_enters"] + medium * counters["medium_tests"]
+             + material * counters["surface_hits"] + noise * counters["noise_calls"] + 4 * counters["texel_fetches"])
+    return total / n + fb / max(1, spp)
+
+
+# ----------------------------------------------------------------------------- libraries
+_host_lib = None
+_hip_lib = None
+
+
+def host_lib() -> C.CDLL:
+    """librtk_host.so: scene construction + flattening (no GPU needed)."""
+    global _host_lib
+    if _host_lib is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise RuntimeError(f"{HOST_LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(HOST_LIB_PATH)
+        lib.rtkh_scene_build.restype = C.c_void_p
+        lib.rtkh_scene_build.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p]
+        lib.rtkh_scene_load.restype = C.c_void_p
+        lib.rtkh_scene_load.argtypes = [C.c_char_p]
+        lib.rtkh_scene_free.argtypes = [C.c_void_p]
+        lib.rtkh_scene_desc.restype = C.c_void_p
+        lib.rtkh_scene_desc.argtypes = [C.c_void_p]
+        lib.rtkh_scene_save.argtypes = [C.c_void_p, C.c_char_p]
+        lib.rtkh_scene_rng_draws.restype = C.c_uint64
+        lib.rtkh_scene_rng_draws.argtypes = [C.c_void_p]
+        lib.rtkh_scene_camera.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Camera)]
+        _host_lib = lib
+    return _host_lib
+
+
+def hip_lib() -> C.CDLL:
+    """librtk_hip.so: the kernels + C ABI.  Raises if it was not built."""
+    global _hip_lib
+    if _hip_lib is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise RuntimeError(f"{HIP_LIB_PATH} not built: the HIP extension is required, there is no CPU path")
+        lib = C.CDLL(HIP_LIB_PATH)
+        lib.rtk_abi_version.restype = C.c_int
+        lib.rtk_last_error.restype = C.c_char_p
+        lib.rtk_init.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        lib.rtk_destroy.argtypes = [C.c_void_p]
+        lib.rtk_scene_upload.argtypes = [C.c_void_p, C.c_void_p]
+        lib.rtk_tiles_per_rank.restype = C.c_int64
+        lib.rtk_tiles_per_rank.argtypes = [C.c_int, C.c_int, C.c_int]
+        lib.rtk_render_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.rtk_tiles_unpermute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.rtk_render_host.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.rtk_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        lib.rtk_kernel_name.restype = C.c_char_p
+        lib.rtk_kernel_name.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        if lib.rtk_abi_version() != RTK_ABI_VERSION:
+            raise RuntimeError("librtk_hip.so ABI version mismatch")
+        _hip_lib = lib
+    return _hip_lib
+
+
+def tiles_per_rank(width: int, height: int, n_ranks: int) -> int:
+    """Same arithmetic as rtk_tiles_per_rank (usable without the HIP library)."""
+    tiles = ((width + 7) // 8) * ((height + 7) // 8)
+    return (tiles + n_ranks - 1) // n_ranks
+
+
+# ----------------------------------------------------------------------------- scenes
+class Scene:
+    """A flattened scene (rtk_scene_desc) owned by librtk_host.so."""
+
+    def __init__(self, handle: int, name: str):
+        if not handle:
+            raise ValueError(f"could not build/load scene {name!r}")
+        self._h = handle
+        self.name = name
+
+    @classmethod
+    def build(cls, name: str, scene_seed: int = SCENE_SEED, image_file: Optional[str] = None) -> "Scene":
+        h = host_lib().rtkh_scene_build(name.encode(), scene_seed, (image_file or "").encode())
+        return cls(h, name)
+
+    @classmethod
+    def load(cls, path: str) -> "Scene":
+        return cls(host_lib().rtkh_scene_load(path.encode()), os.path.basename(path))
+
+    @property
+    def desc_ptr(self) -> int:
+        return host_lib().rtkh_scene_desc(self._h)
+
+    def save(self, path: str) -> None:
+        if host_lib().rtkh_scene_save(self._h, path.encode()) != 0:
+            raise IOError(f"cannot write {path}")
+
+    def camera(self, width: int = 0, height: int = 0, spp: int = 0, depth: int = 0) -> Camera:
+        cam = Camera()
+        rc = host_lib().rtkh_scene_camera(self._h, width, height, spp, depth, C.byref(cam))
+        if rc != 0:
+            raise ValueError(f"cannot derive a {width}x{height} camera for {self.name} (rc={rc})")
+        return cam
+
+    def close(self) -> None:
+        if self._h:
+            host_lib().rtkh_scene_free(self._h)
+            self._h = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def write_synthetic_earth(path: str, width: int = 1024, height: int = 512) -> str:
+    """Procedural RGB8 texture standing in for earthmap.jpg (binary PPM)."""
+    import numpy as np
+
+    y, x = np.mgrid[0:height, 0:width]
+    lon = x / width * 2 * np.pi
+    lat = (y / height - 0.5) * np.pi
+    land = np.sin(3 * lon) * np.cos(2 * lat) + 0.5 * np.sin(7 * lon + 1.3) * np.sin(5 * lat) + 0.25 * np.cos(13 * lon * np.cos(lat))
+    r = np.where(land > 0.15, 60 + 120 * np.clip(land, 0, 1), 20)
+    g = np.where(land > 0.15, 110 + 90 * np.clip(1 - land, 0, 1), 60 + 40 * np.cos(lat))
+    b = np.where(land > 0.15, 40, 150 + 80 * np.cos(lat))
+    img = np.stack([r, g, b], -1).clip(0, 255).astype(np.uint8)
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (width, height))
+        f.write(img.tobytes())
+    return path
+
+
+# ----------------------------------------------------------------------------- renderer
+class Renderer:
+    """One rtk_ctx bound to a HIP device.  Raises RtkError when no gfx950 device is usable."""
+
+    def __init__(self, device: int = 0):
+        self._lib = hip_lib()
+        ctx = C.c_void_p()
+        self._check(self._lib.rtk_init(device, C.byref(ctx)))
+        self._ctx = ctx
+        self.device = device
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise RtkError(rc, self._lib.rtk_last_error().decode())
+
+    def upload(self, scene: Scene) -> None:
+        self._check(self._lib.rtk_scene_upload(self._ctx, scene.desc_ptr))
+
+    def scene_info(self) -> dict:
+        n, b64, b32 = C.c_int32(), C.c_int64(), C.c_int64()
+        self._check(self._lib.rtk_scene_info(self._ctx, C.byref(n), C.byref(b64), C.byref(b32)))
+        return {"program_ops": n.value, "bytes_f64": b64.value, "bytes_f32": b32.value}
+
+    def kernel_name(self, real_mode: int = RTK_REAL_F64, variant: int = 0) -> str:
+        return self._lib.rtk_kernel_name(self._ctx, real_mode, variant).decode()
+
+    def render_device(self, cam: Camera, d_linear: int, d_rgb8: int = 0, *, seed: int = RENDER_SEED, real_mode: int = RTK_REAL_F64,
+                      rank: int = 0, n_ranks: int = 1, d_counters: int = 0, variant: int = 0, stream: int = 0) -> None:
+        """Enqueue the render kernel; all pointers are raw device addresses, nothing synchronises."""
+        opts = RenderOpts(seed, real_mode, rank, n_ranks, 1 if d_counters else 0, variant, stream or None)
+        self._check(self._lib.rtk_render_device(self._ctx, C.byref(cam), C.byref(opts), d_linear or None, d_rgb8 or None, d_counters or None))
+
+    def unpermute(self, width: int, height: int, n_ranks: int, real_mode: int, d_gathered: int, d_linear: int, d_rgb8: int = 0, stream: int = 0) -> None:
+        self._check(self._lib.rtk_tiles_unpermute(self._ctx, width, height, n_ranks, real_mode, d_gathered, d_linear or None, d_rgb8 or None, stream or None))
+
+    def render_host(self, cam: Camera, *, seed: int = RENDER_SEED, real_mode: int = RTK_REAL_F64, count: bool = False, variant: int = 0):
+        """Render the whole image and return (linear float64 HxWx3, rgb8 HxWx3, counters dict | None)."""
+        import numpy as np
+
+        h, w = cam.image_height, cam.image_width
+        linear = np.zeros((h, w, 3), np.float64)
+        rgb8 = np.zeros((h, w, 3), np.uint8)
+        counters = WorkCounters()
+        opts = RenderOpts(seed, real_mode, 0, 1, 1 if count else 0, variant, None)
+        self._check(self._lib.rtk_render_host(self._ctx, C.byref(cam), C.byref(opts), linear.ctypes.data, rgb8.ctypes.data,
+                                              C.byref(counters) if count else None))
+        return linear, rgb8, (counters.as_dict() if count else None)
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None):
+            self._lib.rtk_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,593 @@
+// rtk_api.cpp -- implementation of the C ABI in include/rtk.h (host side of
+// librtk_hip.so; compiled by hipcc).  It validates an rtk_scene_desc, compiles
+// the scene graph into the linear traversal program of rtk_device_layout.h,
+// uploads f64 and f32 images of it to HBM and enqueues the kernels of
+// rtk_trace.hip.  There is no host rendering path: without a gfx950 device every
+// compute entry point fails with RTK_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "rtk.h"
+#include "rtk_device_layout.h"
+#include "rtk_trace.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define RTK_HIP(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) return fail(RTK_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+using namespace rtk;
+
+// ---------------------------------------------------------------------------
+// Scene graph -> traversal program
+// ---------------------------------------------------------------------------
+struct ChainStep {
+    bool rotate;
+    int32_t index;  // into translates[] / rotates[]
+    bool operator<(const ChainStep& o) const { return rotate != o.rotate ? rotate < o.rotate : index < o.index; }
+};
+using Chain = std::vector<ChainStep>;
+
+struct Program {
+    std::vector<Op> ops;
+    std::vector<Chain> chains;
+    std::map<Chain, uint32_t> chain_ids;
+    size_t last_label = size_t(-1);  // op index some skip link points at
+    uint32_t features = 0;
+    int n_primitive_ops = 0;
+    std::string error;
+    int error_code = RTK_OK;
+};
+
+constexpr size_t kMaxOps = size_t(1) << 26;
+constexpr int kMaxGraphDepth = 4096;
+
+struct Compiler {
+    const rtk_scene_desc& sc;
+    Program& prog;
+
+    bool bad(int code, const std::string& why) {
+        if (prog.error_code == RTK_OK) {
+            prog.error_code = code;
+            prog.error = why;
+        }
+        return false;
+    }
+    uint32_t chain_id(const Chain& c) {
+        auto it = prog.chain_ids.find(c);
+        if (it != prog.chain_ids.end()) return it->second;
+        uint32_t id = uint32_t(prog.chains.size());
+        prog.chains.push_back(c);
+        prog.chain_ids[c] = id;
+        return id;
+    }
+    uint32_t push(uint32_t kind, uint32_t payload, uint32_t aux) {
+        prog.ops.push_back(Op{make_op(kind, payload), aux});
+        return uint32_t(prog.ops.size()) - 1;
+    }
+    void label_here() { prog.last_label = prog.ops.size(); }
+    // Consecutive chain switches collapse into one op unless a skip link lands
+    // between them.
+    void push_chain(uint32_t chain, uint32_t entries) {
+        if (!prog.ops.empty() && (prog.ops.back().kind_payload & 15u) == OP_CHAIN && prog.last_label != prog.ops.size()) {
+            Op& last = prog.ops.back();
+            last.aux += entries;
+            last.kind_payload = make_op(OP_CHAIN, chain);
+            return;
+        }
+        push(OP_CHAIN, chain, entries);
+    }
+
+    bool emit(int32_t node, const Chain& chain, bool in_medium, int depth) {
+        if (prog.error_code != RTK_OK) return false;
+        if (node < 0 || node >= sc.n_nodes) return bad(RTK_ERR_INVALID, "node index out of range");
+        if (depth > kMaxGraphDepth) return bad(RTK_ERR_INVALID, "scene graph too deep (cycle?)");
+        if (prog.ops.size() > kMaxOps) return bad(RTK_ERR_UNSUPPORTED, "traversal program too large");
+        const rtk_node& n = sc.nodes[node];
+        const uint32_t cid = chain_id(chain);
+        switch (n.kind) {
+            case RTK_NODE_SPHERE:
+                if (n.a < 0 || n.a >= sc.n_spheres) return bad(RTK_ERR_INVALID, "sphere index out of range");
+                push(OP_SPHERE, uint32_t(n.a), cid);
+                prog.n_primitive_ops++;
+                return true;
+            case RTK_NODE_QUAD:
+                if (n.a < 0 || n.a >= sc.n_quads) return bad(RTK_ERR_INVALID, "quad index out of range");
+                push(OP_QUAD, uint32_t(n.a), cid);
+                prog.features |= F_QUAD;
+                prog.n_primitive_ops++;
+                return true;
+            case RTK_NODE_TRIANGLE:
+                if (n.a < 0 || n.a >= sc.n_triangles) return bad(RTK_ERR_INVALID, "triangle index out of range");
+                push(OP_TRI, uint32_t(n.a), cid);
+                prog.features |= F_TRI;
+                prog.n_primitive_ops++;
+                return true;
+            case RTK_NODE_LIST:
+                if (n.a < 0 || n.b < 0 || int64_t(n.a) + n.b > sc.n_list_children) return bad(RTK_ERR_INVALID, "list children out of range");
+                for (int32_t k = 0; k < n.b; k++)
+                    if (!emit(sc.list_children[n.a + k], chain, in_medium, depth + 1)) return false;
+                return true;
+            case RTK_NODE_BVH: {
+                if (n.c < 0 || n.c >= sc.n_bvh_boxes) return bad(RTK_ERR_INVALID, "bvh box index out of range");
+                uint32_t at = push(OP_BOX, uint32_t(n.c), 0);
+                if (!emit(n.a, chain, in_medium, depth + 1)) return false;
+                if (!emit(n.b, chain, in_medium, depth + 1)) return false;
+                prog.ops[at].aux = uint32_t(prog.ops.size());
+                label_here();
+                return true;
+            }
+            case RTK_NODE_TRANSLATE:
+            case RTK_NODE_ROTATE_Y: {
+                const bool rot = n.kind == RTK_NODE_ROTATE_Y;
+                if (n.a < 0 || n.a >= (rot ? sc.n_rotates : sc.n_translates)) return bad(RTK_ERR_INVALID, "transform index out of range");
+                if (int(chain.size()) >= kMaxChain) return bad(RTK_ERR_UNSUPPORTED, "more than 4 nested instance transforms");
+                Chain inner = chain;
+                inner.push_back(ChainStep{rot, n.a});
+                prog.features |= F_XFORM;
+                push_chain(chain_id(inner), 1);
+                if (!emit(n.b, inner, in_medium, depth + 1)) return false;
+                push_chain(cid, 0);
+                return true;
+            }
+            case RTK_NODE_MEDIUM: {
+                if (n.a < 0 || n.a >= sc.n_media) return bad(RTK_ERR_INVALID, "medium index out of range");
+                if (in_medium) return bad(RTK_ERR_UNSUPPORTED, "constant_medium inside the boundary of another constant_medium");
+                prog.features |= F_MEDIA;
+                push(OP_MED_BEGIN, uint32_t(n.a), 0);
+                if (!emit(n.b, chain, true, depth + 1)) return false;
+                uint32_t mid = push(OP_MED_MID, uint32_t(n.a), 0);
+                if (!emit(n.b, chain, true, depth + 1)) return false;
+                push(OP_MED_END, uint32_t(n.a), cid);
+                prog.ops[mid].aux = uint32_t(prog.ops.size());
+                label_here();
+                prog.n_primitive_ops++;
+                return true;
+            }
+        }
+        return bad(RTK_ERR_INVALID, "unknown node kind");
+    }
+};
+
+bool texture_needs_uv(const rtk_scene_desc& sc, int32_t tex, int depth = 0) {
+    if (tex < 0 || tex >= sc.n_textures || depth > 64) return false;
+    const rtk_texture& t = sc.textures[tex];
+    if (t.kind == RTK_TEX_IMAGE || t.kind == RTK_TEX_CHECKER_TRI) return true;
+    if (t.kind == RTK_TEX_CHECKER) return texture_needs_uv(sc, t.even, depth + 1) || texture_needs_uv(sc, t.odd, depth + 1);
+    return false;
+}
+
+int validate_tables(const rtk_scene_desc& sc) {
+    if (sc.abi_version != RTK_ABI_VERSION) return fail(RTK_ERR_INVALID, "scene abi_version %d != %d", sc.abi_version, RTK_ABI_VERSION);
+    if (sc.n_nodes <= 0 || !sc.nodes) return fail(RTK_ERR_INVALID, "scene has no nodes (the reference recurses forever on an empty world, bvh.h:38-43)");
+    for (int32_t i = 0; i < sc.n_textures; i++) {
+        const rtk_texture& t = sc.textures[i];
+        switch (t.kind) {
+            case RTK_TEX_SOLID: break;
+            case RTK_TEX_CHECKER:
+            case RTK_TEX_CHECKER_TRI:
+                // children are emitted before their parent by every flattener, which also rules out cycles
+                if (t.even < 0 || t.even >= i || t.odd < 0 || t.odd >= i) return fail(RTK_ERR_INVALID, "texture %d: child index must precede it", i);
+                break;
+            case RTK_TEX_IMAGE: {
+                if (t.image < 0 || t.image >= sc.n_images) return fail(RTK_ERR_INVALID, "texture %d: image index out of range", i);
+                const rtk_image& im = sc.images[t.image];
+                if (im.width > 0 && im.height > 0 &&
+                    (im.texel_offset < 0 || im.texel_offset + int64_t(im.width) * im.height * 3 > sc.n_texel_bytes))
+                    return fail(RTK_ERR_INVALID, "image %d: texels out of range", t.image);
+                break;
+            }
+            case RTK_TEX_NOISE:
+                if (t.image < 0 || t.image >= sc.n_perlins) return fail(RTK_ERR_INVALID, "texture %d: perlin index out of range", i);
+                break;
+            default: return fail(RTK_ERR_INVALID, "texture %d: unknown kind %d", i, t.kind);
+        }
+    }
+    for (int32_t i = 0; i < sc.n_materials; i++) {
+        const rtk_material& m = sc.materials[i];
+        const bool textured = m.kind == RTK_MAT_LAMBERTIAN || m.kind == RTK_MAT_DIFFUSE_LIGHT || m.kind == RTK_MAT_ISOTROPIC;
+        if (m.kind < RTK_MAT_LAMBERTIAN || m.kind > RTK_MAT_SPECULAR) return fail(RTK_ERR_INVALID, "material %d: unknown kind %d", i, m.kind);
+        if (textured && (m.texture < 0 || m.texture >= sc.n_textures)) return fail(RTK_ERR_INVALID, "material %d: texture index out of range", i);
+    }
+    auto mat_ok = [&](int32_t m) { return m >= 0 && m < sc.n_materials; };
+    for (int32_t i = 0; i < sc.n_spheres; i++)
+        if (!mat_ok(sc.spheres[i].material)) return fail(RTK_ERR_INVALID, "sphere %d: material out of range", i);
+    for (int32_t i = 0; i < sc.n_quads; i++)
+        if (!mat_ok(sc.quads[i].material)) return fail(RTK_ERR_INVALID, "quad %d: material out of range", i);
+    for (int32_t i = 0; i < sc.n_triangles; i++)
+        if (!mat_ok(sc.triangles[i].material)) return fail(RTK_ERR_INVALID, "triangle %d: material out of range", i);
+    for (int32_t i = 0; i < sc.n_media; i++)
+        if (!mat_ok(sc.media[i].material)) return fail(RTK_ERR_INVALID, "medium %d: material out of range", i);
+    return RTK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Device image of a scene for one arithmetic type
+// ---------------------------------------------------------------------------
+template <typename real>
+struct DeviceScene {
+    std::vector<void*> allocations;
+    SceneView<real> view{};
+    int64_t bytes = 0;
+
+    void release() {
+        for (void* p : allocations) (void)hipFree(p);
+        allocations.clear();
+        view = SceneView<real>{};
+        bytes = 0;
+    }
+    template <typename T>
+    int upload(const std::vector<T>& host, const T** out) {
+        *out = nullptr;
+        if (host.empty()) return RTK_OK;
+        void* d = nullptr;
+        RTK_HIP(hipMalloc(&d, host.size() * sizeof(T)));
+        allocations.push_back(d);
+        RTK_HIP(hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+        bytes += int64_t(host.size() * sizeof(T));
+        *out = static_cast<const T*>(d);
+        return RTK_OK;
+    }
+};
+
+template <typename real>
+void store3(real* dst, const rtk_vec3& v) {
+    dst[0] = real(v.x);
+    dst[1] = real(v.y);
+    dst[2] = real(v.z);
+}
+
+template <typename real>
+int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScene<real>& out) {
+    out.release();
+    std::vector<BoxRec<real>> boxes(sc.n_bvh_boxes);
+    for (int32_t i = 0; i < sc.n_bvh_boxes; i++) {
+        const rtk_aabb& b = sc.bvh_boxes[i];
+        boxes[i] = BoxRec<real>{real(b.xmin), real(b.xmax), real(b.ymin), real(b.ymax), real(b.zmin), real(b.zmax), {real(0), real(0)}};
+    }
+    std::vector<SphereRec<real>> spheres(sc.n_spheres);
+    for (int32_t i = 0; i < sc.n_spheres; i++) {
+        const rtk_sphere& s = sc.spheres[i];
+        const bool moving = s.center_dir.x != 0 || s.center_dir.y != 0 || s.center_dir.z != 0;
+        spheres[i] = SphereRec<real>{real(s.center0.x), real(s.center0.y), real(s.center0.z), real(s.radius), real(s.center_dir.x), real(s.center_dir.y),
+                                     real(s.center_dir.z), s.material, moving ? 1 : 0};
+    }
+    std::vector<QuadRec<real>> quads(sc.n_quads);
+    for (int32_t i = 0; i < sc.n_quads; i++) {
+        const rtk_quad& q = sc.quads[i];
+        QuadRec<real>& r = quads[i];
+        store3(r.Q, q.Q); store3(r.u, q.u); store3(r.v, q.v); store3(r.w, q.w); store3(r.n, q.normal);
+        r.D = real(q.D);
+        r.material = q.material;
+        r._pad = 0;
+    }
+    std::vector<TriRec<real>> tris(sc.n_triangles);
+    for (int32_t i = 0; i < sc.n_triangles; i++) {
+        const rtk_triangle& t = sc.triangles[i];
+        TriRec<real>& r = tris[i];
+        // v0v1 = p1 - p0, v0v2 = p2 - p0 (triangle.h:67-68) in double, then to `real`
+        store3(r.p0, t.p0);
+        store3(r.e1, rtk_vec3{t.p1.x - t.p0.x, t.p1.y - t.p0.y, t.p1.z - t.p0.z});
+        store3(r.e2, rtk_vec3{t.p2.x - t.p0.x, t.p2.y - t.p0.y, t.p2.z - t.p0.z});
+        store3(r.n, t.normal);
+        for (int k = 0; k < 2; k++) { r.uv0[k] = t.uv0[k]; r.uv1[k] = t.uv1[k]; r.uv2[k] = t.uv2[k]; }
+        r.material = t.material;
+        r._pad = 0;
+    }
+    std::vector<MediumRec<real>> media(sc.n_media);
+    for (int32_t i = 0; i < sc.n_media; i++) media[i] = MediumRec<real>{real(sc.media[i].neg_inv_density), sc.media[i].material, 0};
+
+    std::vector<MaterialRec<real>> mats(sc.n_materials);
+    for (int32_t i = 0; i < sc.n_materials; i++) {
+        const rtk_material& m = sc.materials[i];
+        MaterialRec<real>& r = mats[i];
+        store3(r.albedo, m.albedo);
+        r.param = real(m.param);
+        r.kind = m.kind;
+        r.tex = -1;
+        r.needs_uv = 0;
+        r._pad = 0;
+        const bool textured = m.kind == RTK_MAT_LAMBERTIAN || m.kind == RTK_MAT_DIFFUSE_LIGHT || m.kind == RTK_MAT_ISOTROPIC;
+        if (textured) {
+            const rtk_texture& t = sc.textures[m.texture];
+            if (t.kind == RTK_TEX_SOLID) {
+                store3(r.albedo, t.color);  // solid_color::value is the constant (texture.h:26): fold it in
+            } else {
+                r.tex = m.texture;
+                r.needs_uv = texture_needs_uv(sc, m.texture) ? 1 : 0;
+            }
+        }
+    }
+    std::vector<TextureRec<real>> texs(sc.n_textures);
+    for (int32_t i = 0; i < sc.n_textures; i++) {
+        const rtk_texture& t = sc.textures[i];
+        TextureRec<real>& r = texs[i];
+        store3(r.color, t.color);
+        r.param = real(t.param);
+        r.kind = t.kind; r.even = t.even; r.odd = t.odd; r.image = t.image;
+    }
+    std::vector<ImageRec> images(sc.n_images);
+    for (int32_t i = 0; i < sc.n_images; i++) images[i] = ImageRec{sc.images[i].width, sc.images[i].height, sc.images[i].texel_offset};
+    std::vector<uint8_t> texels(sc.texels, sc.texels + sc.n_texel_bytes);
+    std::vector<PerlinRec<real>> perlins(sc.n_perlins);
+    for (int32_t i = 0; i < sc.n_perlins; i++) {
+        for (int k = 0; k < 256; k++) {
+            for (int c = 0; c < 3; c++) perlins[i].randvec[k][c] = real(sc.perlins[i].randvec[k][c]);
+            perlins[i].perm_x[k] = sc.perlins[i].perm_x[k];
+            perlins[i].perm_y[k] = sc.perlins[i].perm_y[k];
+            perlins[i].perm_z[k] = sc.perlins[i].perm_z[k];
+        }
+    }
+    std::vector<ChainRec<real>> chains(prog.chains.size());
+    for (size_t i = 0; i < prog.chains.size(); i++) {
+        ChainRec<real>& r = chains[i];
+        std::memset(&r, 0, sizeof r);
+        r.count = int32_t(prog.chains[i].size());
+        for (int k = 0; k < r.count; k++) {
+            const ChainStep& st = prog.chains[i][k];
+            r.is_rotate[k] = st.rotate ? 1 : 0;
+            if (st.rotate) {
+                r.a[k] = real(sc.rotates[st.index].sin_theta);
+                r.b[k] = real(sc.rotates[st.index].cos_theta);
+            } else {
+                r.a[k] = real(sc.translates[st.index].offset.x);
+                r.b[k] = real(sc.translates[st.index].offset.y);
+                r.c[k] = real(sc.translates[st.index].offset.z);
+            }
+        }
+    }
+    std::vector<LightRec<real>> lights(sc.n_lights);
+    for (int32_t i = 0; i < sc.n_lights; i++) {
+        store3(lights[i].position, sc.lights[i].position);
+        store3(lights[i].intensity, sc.lights[i].intensity);
+        lights[i].size = real(sc.lights[i].size);
+    }
+    int rc;
+    if ((rc = out.upload(prog.ops, &out.view.ops)) != RTK_OK) return rc;
+    if ((rc = out.upload(boxes, &out.view.boxes)) != RTK_OK) return rc;
+    if ((rc = out.upload(spheres, &out.view.spheres)) != RTK_OK) return rc;
+    if ((rc = out.upload(quads, &out.view.quads)) != RTK_OK) return rc;
+    if ((rc = out.upload(tris, &out.view.tris)) != RTK_OK) return rc;
+    if ((rc = out.upload(media, &out.view.media)) != RTK_OK) return rc;
+    if ((rc = out.upload(mats, &out.view.materials)) != RTK_OK) return rc;
+    if ((rc = out.upload(texs, &out.view.textures)) != RTK_OK) return rc;
+    if ((rc = out.upload(images, &out.view.images)) != RTK_OK) return rc;
+    if ((rc = out.upload(texels, &out.view.texels)) != RTK_OK) return rc;
+    if ((rc = out.upload(perlins, &out.view.perlins)) != RTK_OK) return rc;
+    if ((rc = out.upload(chains, &out.view.chains)) != RTK_OK) return rc;
+    if ((rc = out.upload(lights, &out.view.lights)) != RTK_OK) return rc;
+    out.view.n_ops = int32_t(prog.ops.size());
+    out.view.n_lights = sc.n_lights;
+    return RTK_OK;
+}
+
+template <typename real>
+CameraRec<real> to_device_camera(const rtk_camera& c) {
+    CameraRec<real> r;
+    store3(r.background, c.background);
+    store3(r.center, c.center);
+    store3(r.pixel00, c.pixel00_loc);
+    store3(r.du, c.pixel_delta_u);
+    store3(r.dv, c.pixel_delta_v);
+    store3(r.disk_u, c.defocus_disk_u);
+    store3(r.disk_v, c.defocus_disk_v);
+    r.defocus_angle = real(c.defocus_angle);
+    r.samples_scale = real(c.pixel_samples_scale);
+    r.width = c.image_width;
+    r.height = c.image_height;
+    r.spp = c.samples_per_pixel;
+    r.max_depth = c.max_depth;
+    return r;
+}
+
+}  // namespace
+
+struct rtk_ctx {
+    int device = 0;
+    bool has_scene = false;
+    uint32_t features = 0;
+    int32_t n_ops = 0;
+    DeviceScene<double> scene64;
+    DeviceScene<float> scene32;
+};
+
+extern "C" {
+
+int rtk_abi_version(void) { return RTK_ABI_VERSION; }
+
+const char* rtk_last_error(void) { return g_error.c_str(); }
+
+int rtk_init(int device, rtk_ctx** out_ctx) {
+    if (!out_ctx) return fail(RTK_ERR_INVALID, "rtk_init: out_ctx is null");
+    *out_ctx = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(RTK_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(RTK_ERR_INVALID, "rtk_init: device %d out of range (0..%d)", device, count - 1);
+    hipDeviceProp_t prop;
+    RTK_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RTK_ERR_NO_DEVICE, "device %d is %s; the kernels are built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    RTK_HIP(hipSetDevice(device));
+    auto* ctx = new rtk_ctx;
+    ctx->device = device;
+    *out_ctx = ctx;
+    return RTK_OK;
+}
+
+int rtk_destroy(rtk_ctx* ctx) {
+    if (!ctx) return RTK_OK;
+    (void)hipSetDevice(ctx->device);
+    ctx->scene64.release();
+    ctx->scene32.release();
+    delete ctx;
+    return RTK_OK;
+}
+
+int rtk_scene_upload(rtk_ctx* ctx, const rtk_scene_desc* scene) {
+    if (!ctx || !scene) return fail(RTK_ERR_INVALID, "rtk_scene_upload: null argument");
+    int rc = validate_tables(*scene);
+    if (rc != RTK_OK) return rc;
+    Program prog;
+    Compiler comp{*scene, prog};
+    comp.chain_id(Chain{});  // chain 0 = world space
+    comp.emit(scene->root, Chain{}, false, 0);
+    if (prog.error_code != RTK_OK) return fail(prog.error_code, "rtk_scene_upload: %s", prog.error.c_str());
+    if (prog.n_primitive_ops == 0) return fail(RTK_ERR_INVALID, "rtk_scene_upload: no primitive reachable from the root");
+    prog.ops.push_back(Op{make_op(OP_END, 0), 0});
+    for (int32_t i = 0; i < scene->n_materials; i++) {
+        const rtk_material& m = scene->materials[i];
+        if (m.kind == RTK_MAT_DIFFUSE_LIGHT || m.kind == RTK_MAT_ISOTROPIC || m.kind == RTK_MAT_SPECULAR) prog.features |= F_EXOTIC_MAT;
+        const bool textured = m.kind == RTK_MAT_LAMBERTIAN || m.kind == RTK_MAT_DIFFUSE_LIGHT || m.kind == RTK_MAT_ISOTROPIC;
+        if (textured && scene->textures[m.texture].kind != RTK_TEX_SOLID) prog.features |= F_TEXTURE;
+    }
+    if (scene->n_lights > 0) prog.features |= F_LIGHTS;
+
+    RTK_HIP(hipSetDevice(ctx->device));
+    ctx->has_scene = false;
+    if ((rc = build_device_scene<double>(*scene, prog, ctx->scene64)) != RTK_OK) return rc;
+    if ((rc = build_device_scene<float>(*scene, prog, ctx->scene32)) != RTK_OK) return rc;
+    ctx->features = prog.features;
+    ctx->n_ops = int32_t(prog.ops.size());
+    ctx->has_scene = true;
+    return RTK_OK;
+}
+
+int64_t rtk_tiles_per_rank(int image_width, int image_height, int n_ranks) {
+    if (image_width <= 0 || image_height <= 0 || n_ranks <= 0) return 0;
+    const int64_t tiles = int64_t((image_width + RTK_TILE_W - 1) / RTK_TILE_W) * ((image_height + RTK_TILE_H - 1) / RTK_TILE_H);
+    return (tiles + n_ranks - 1) / n_ranks;
+}
+
+int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts* opts, void* d_linear, uint8_t* d_rgb8, rtk_work_counters* d_counters) {
+    if (!ctx || !cam || !opts) return fail(RTK_ERR_INVALID, "rtk_render_device: null argument");
+    if (!ctx->has_scene) return fail(RTK_ERR_NO_SCENE, "rtk_render_device: no scene uploaded");
+    if (cam->image_width <= 0 || cam->image_height <= 0 || cam->samples_per_pixel <= 0 || cam->max_depth < 0)
+        return fail(RTK_ERR_INVALID, "rtk_render_device: bad camera dimensions");
+    if (opts->n_ranks < 1 || opts->rank < 0 || opts->rank >= opts->n_ranks) return fail(RTK_ERR_INVALID, "rtk_render_device: bad rank %d of %d", opts->rank, opts->n_ranks);
+    if (opts->n_ranks > 1 && d_rgb8) return fail(RTK_ERR_INVALID, "rtk_render_device: d_rgb8 must be null when n_ranks > 1 (use rtk_tiles_unpermute)");
+    if (opts->count_work && !d_counters) return fail(RTK_ERR_INVALID, "rtk_render_device: count_work needs d_counters");
+    if (opts->real_mode != RTK_REAL_F64 && opts->real_mode != RTK_REAL_F32) return fail(RTK_ERR_INVALID, "rtk_render_device: unknown real_mode %d", opts->real_mode);
+    RTK_HIP(hipSetDevice(ctx->device));
+    TileMap tm;
+    tm.tiles_x = (cam->image_width + RTK_TILE_W - 1) / RTK_TILE_W;
+    tm.tiles_y = (cam->image_height + RTK_TILE_H - 1) / RTK_TILE_H;
+    tm.rank = opts->rank;
+    tm.n_ranks = opts->n_ranks;
+    tm.n_tiles_local = int32_t(rtk_tiles_per_rank(cam->image_width, cam->image_height, opts->n_ranks));
+    tm.compact = opts->n_ranks > 1 ? 1 : 0;
+    hipStream_t stream = static_cast<hipStream_t>(opts->stream);
+    auto* counters = reinterpret_cast<unsigned long long*>(d_counters);
+    hipError_t e;
+    if (opts->real_mode == RTK_REAL_F64)
+        e = launch_render<double>(ctx->scene64.view, to_device_camera<double>(*cam), tm, opts->seed, ctx->features, opts->count_work != 0, d_linear, d_rgb8,
+                                  counters, stream);
+    else
+        e = launch_render<float>(ctx->scene32.view, to_device_camera<float>(*cam), tm, opts->seed, ctx->features, opts->count_work != 0, d_linear, d_rgb8,
+                                 counters, stream);
+    if (e != hipSuccess) return fail(RTK_ERR_HIP, "render kernel launch failed: %s", hipGetErrorString(e));
+    return RTK_OK;
+}
+
+int rtk_tiles_unpermute(rtk_ctx* ctx, int image_width, int image_height, int n_ranks, int real_mode, const void* d_gathered, void* d_linear, uint8_t* d_rgb8,
+                        void* stream) {
+    if (!ctx || !d_gathered || image_width <= 0 || image_height <= 0 || n_ranks < 1) return fail(RTK_ERR_INVALID, "rtk_tiles_unpermute: bad argument");
+    RTK_HIP(hipSetDevice(ctx->device));
+    const long long tpr = rtk_tiles_per_rank(image_width, image_height, n_ranks);
+    hipError_t e = real_mode == RTK_REAL_F64
+                       ? launch_unpermute<double>(d_gathered, image_width, image_height, n_ranks, tpr, d_linear, d_rgb8, static_cast<hipStream_t>(stream))
+                       : launch_unpermute<float>(d_gathered, image_width, image_height, n_ranks, tpr, d_linear, d_rgb8, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(RTK_ERR_HIP, "unpermute kernel launch failed: %s", hipGetErrorString(e));
+    return RTK_OK;
+}
+
+int rtk_render_host(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts* opts, double* h_linear, uint8_t* h_rgb8, rtk_work_counters* counters) {
+    if (!ctx || !cam || !opts) return fail(RTK_ERR_INVALID, "rtk_render_host: null argument");
+    if (opts->n_ranks != 1) return fail(RTK_ERR_INVALID, "rtk_render_host renders whole images (n_ranks must be 1)");
+    RTK_HIP(hipSetDevice(ctx->device));
+    const size_t n = size_t(cam->image_width) * cam->image_height * 3;
+    const size_t elem = opts->real_mode == RTK_REAL_F64 ? sizeof(double) : sizeof(float);
+    void* d_linear = nullptr;
+    uint8_t* d_rgb8 = nullptr;
+    rtk_work_counters* d_cnt = nullptr;
+    int rc = RTK_OK;
+    auto cleanup = [&]() {
+        if (d_linear) (void)hipFree(d_linear);
+        if (d_rgb8) (void)hipFree(d_rgb8);
+        if (d_cnt) (void)hipFree(d_cnt);
+    };
+#define RTK_HIP_CLEAN(call)                                                                       \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            cleanup();                                                                            \
+            return fail(RTK_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));               \
+        }                                                                                         \
+    } while (0)
+    RTK_HIP_CLEAN(hipMalloc(&d_linear, n * elem));
+    RTK_HIP_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_rgb8), n));
+    rtk_render_opts o = *opts;
+    o.count_work = counters ? 1 : 0;
+    if (counters) {
+        RTK_HIP_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_cnt), sizeof(rtk_work_counters)));
+        RTK_HIP_CLEAN(hipMemsetAsync(d_cnt, 0, sizeof(rtk_work_counters), static_cast<hipStream_t>(o.stream)));
+    }
+    rc = rtk_render_device(ctx, cam, &o, d_linear, d_rgb8, d_cnt);
+    if (rc != RTK_OK) {
+        cleanup();
+        return rc;
+    }
+    RTK_HIP_CLEAN(hipStreamSynchronize(static_cast<hipStream_t>(o.stream)));
+    if (h_linear) {
+        if (opts->real_mode == RTK_REAL_F64) {
+            RTK_HIP_CLEAN(hipMemcpy(h_linear, d_linear, n * sizeof(double), hipMemcpyDeviceToHost));
+        } else {
+            std::vector<float> tmp(n);
+            RTK_HIP_CLEAN(hipMemcpy(tmp.data(), d_linear, n * sizeof(float), hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < n; k++) h_linear[k] = double(tmp[k]);
+        }
+    }
+    if (h_rgb8) RTK_HIP_CLEAN(hipMemcpy(h_rgb8, d_rgb8, n, hipMemcpyDeviceToHost));
+    if (counters) RTK_HIP_CLEAN(hipMemcpy(counters, d_cnt, sizeof(rtk_work_counters), hipMemcpyDeviceToHost));
+    cleanup();
+    return RTK_OK;
+}
+
+int rtk_scene_info(rtk_ctx* ctx, int32_t* n_program_ops, int64_t* bytes_f64, int64_t* bytes_f32) {
+    if (!ctx || !ctx->has_scene) return fail(RTK_ERR_NO_SCENE, "rtk_scene_info: no scene uploaded");
+    if (n_program_ops) *n_program_ops = ctx->n_ops;
+    if (bytes_f64) *bytes_f64 = ctx->scene64.bytes;
+    if (bytes_f32) *bytes_f32 = ctx->scene32.bytes;
+    return RTK_OK;
+}
+
+const char* rtk_kernel_name(rtk_ctx* ctx, int real_mode, int variant) {
+    (void)variant;
+    if (!ctx || !ctx->has_scene) return "";
+    return render_kernel_name(real_mode == RTK_REAL_F64, ctx->features, false);
+}
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+// rtk_device_layout.h -- how an uploaded scene lies in HBM, shared by the host
+// side of librtk_hip.so (rtk_api.cpp builds and uploads it) and the kernels
+// (rtk_trace.hip reads it).  Everything is templated on `real` (double for the
+// parity mode, float for the throughput mode).
+//
+// The scene graph of rtk_scene_desc is compiled into a linear TRAVERSAL PROGRAM:
+// one 8-byte op per visit, laid out in exactly the order the reference's
+// recursion visits things (bvh.h:64-72: box test, then left subtree, then right
+// subtree, both always), with a skip link on every box op.  Executing the
+// program from op 0 to OP_END with "on a failed box test jump to op.aux" performs
+// the same sequence of aabb::hit / primitive hit calls as the reference, with no
+// traversal stack at all:
+//
+//   hittable_list          -> its children's programs, concatenated
+//   bvh_node               -> OP_BOX(box, skip) . left . right          skip -> after right
+//   sphere/quad/triangle   -> OP_SPHERE / OP_QUAD / OP_TRI (payload = record index, aux = chain)
+//   translate / rotate_y   -> OP_CHAIN(child chain) . child . OP_CHAIN(parent chain)
+//   constant_medium        -> OP_MED_BEGIN . boundary . OP_MED_MID(skip) . boundary . OP_MED_END
+//
+// A "chain" is the sequence of instance transforms from world space down to a
+// primitive; the kernel keeps only the world-space ray and re-derives the
+// object-space ray from it whenever the chain changes (bit-identical to the
+// reference's nested ray construction, hittable.h:46-58,101-139, because the same
+// operations are applied in the same order).  A shared subtree (DAG) is simply
+// emitted once per use.
+#ifndef RTK_DEVICE_LAYOUT_H
+#define RTK_DEVICE_LAYOUT_H
+
+#include <stdint.h>
+
+namespace rtk {
+
+enum OpKind : uint32_t {
+    OP_END = 0,
+    OP_BOX = 1,        // payload = box index, aux = pc to continue at when the slab test fails
+    OP_SPHERE = 2,     // payload = sphere index, aux = chain id
+    OP_QUAD = 3,       // payload = quad index, aux = chain id
+    OP_TRI = 4,        // payload = triangle index, aux = chain id
+    OP_CHAIN = 5,      // payload = chain id to make current, aux = number of transform entries it stands for
+    OP_MED_BEGIN = 6,  // payload = medium index
+    OP_MED_MID = 7,    // payload = medium index, aux = pc after the matching OP_MED_END
+    OP_MED_END = 8     // payload = medium index, aux = chain id
+};
+
+struct Op {
+    uint32_t kind_payload;  // kind in bits 0..3, payload in bits 4..31
+    uint32_t aux;
+};
+inline constexpr uint32_t make_op(uint32_t kind, uint32_t payload) { return kind | (payload << 4); }
+
+constexpr uint32_t kNoHit = 0xFFFFFFFFu;
+constexpr int kMaxChain = 4;
+
+// Scene feature bits: which op kinds / shading paths a scene needs.  The host
+// picks the leanest kernel instantiation that covers the scene's mask.
+enum Feature : uint32_t {
+    F_QUAD = 1u << 0,
+    F_TRI = 1u << 1,
+    F_XFORM = 1u << 2,
+    F_MEDIA = 1u << 3,
+    F_TEXTURE = 1u << 4,  // any non-solid texture (checker, checker_tri, image, noise)
+    F_LIGHTS = 1u << 5,
+    F_EXOTIC_MAT = 1u << 6  // isotropic / specular / diffuse_light
+};
+constexpr uint32_t kFeatLean = 0;                       // spheres + lambertian/metal/dielectric with solid colours
+constexpr uint32_t kFeatAll = 0x7F;
+
+template <typename real>
+struct alignas(16) BoxRec {  // aabb of a bvh_node (aabb.h:12)
+    real xmin, xmax, ymin, ymax, zmin, zmax;
+    real _pad[2];            // f64: 64 B, f32: 32 B -> whole records per 16-B load
+};
+
+template <typename real>
+struct alignas(16) SphereRec {  // sphere.h:60-64
+    real cx, cy, cz, radius;
+    real dx, dy, dz;            // center motion (center2 - center1); 0 for a static sphere
+    int32_t material;
+    int32_t moving;             // dx,dy,dz not all zero
+};
+
+template <typename real>
+struct alignas(16) QuadRec {  // quad.h:76-83
+    real Q[3], u[3], v[3], w[3], n[3], D;
+    int32_t material, _pad;
+};
+
+template <typename real>
+struct alignas(16) TriRec {  // triangle.h:124-143; e1 = p1-p0, e2 = p2-p0 are what hit() recomputes per call
+    real p0[3], e1[3], e2[3], n[3];
+    float uv0[2], uv1[2], uv2[2];
+    int32_t material, _pad;
+};
+
+template <typename real>
+struct alignas(16) MediumRec {  // constant_medium.h:57-59
+    real neg_inv_density;
+    int32_t material, _pad;
+};
+
+template <typename real>
+struct alignas(16) MaterialRec {  // material.h
+    real albedo[3], param;
+    int32_t kind, tex;
+    int32_t needs_uv, _pad;       // texture (transitively) reads rec.u/rec.v
+};
+
+template <typename real>
+struct alignas(16) TextureRec {  // texture.h
+    real color[3], param;
+    int32_t kind, even, odd, image;
+};
+
+struct ImageRec {  // rtw_stb_image.h:84-90
+    int32_t width, height;
+    int64_t texel_offset;
+};
+
+template <typename real>
+struct PerlinRec {  // perlin.h:52-57
+    real randvec[256][3];
+    int32_t perm_x[256], perm_y[256], perm_z[256];
+};
+
+template <typename real>
+struct ChainRec {  // instance transforms from world space to the primitive, outermost first
+    int32_t count;
+    int32_t is_rotate[kMaxChain];
+    real a[kMaxChain], b[kMaxChain], c[kMaxChain];  // translate: offset xyz; rotate_y: a = sin, b = cos
+};
+
+template <typename real>
+struct LightRec {  // point_light.h:24-27
+    real position[3], intensity[3], size;
+};
+
+template <typename real>
+struct CameraRec {  // Camera.txt:122-131
+    real background[3], center[3], pixel00[3], du[3], dv[3], disk_u[3], disk_v[3];
+    real defocus_angle, samples_scale;
+    int32_t width, height, spp, max_depth;
+};
+
+template <typename real>
+struct SceneView {  // device pointers, passed to the kernel by value
+    const Op* ops;
+    const BoxRec<real>* boxes;
+    const SphereRec<real>* spheres;
+    const QuadRec<real>* quads;
+    const TriRec<real>* tris;
+    const MediumRec<real>* media;
+    const MaterialRec<real>* materials;
+    const TextureRec<real>* textures;
+    const ImageRec* images;
+    const uint8_t* texels;
+    const PerlinRec<real>* perlins;
+    const ChainRec<real>* chains;
+    const LightRec<real>* lights;
+    int32_t n_ops, n_lights;
+};
+
+struct TileMap {  // which tiles this launch renders and where the pixels go
+    int32_t tiles_x, tiles_y, n_tiles_local;
+    int32_t rank, n_ranks;
+    int32_t compact;  // 1: write [local_tile][3][64] reals, 0: write the row-major image
+};
+
+// Indices into the uint64 work-counter block (same order as rtk_work_counters).
+enum CounterSlot {
+    C_SAMPLES, C_SEGMENTS, C_BOX, C_SPHERE, C_QUAD, C_TRI, C_XFORM, C_MEDIUM, C_SURFACE, C_NOISE, C_TEXEL, C_RNG, C_COUNT
+};
+
+}  // namespace rtk
+
+#endif  // RTK_DEVICE_LAYOUT_H

@@ -1,0 +1,761 @@
+// rtk_trace.hip -- the per-pixel sample loop of camera::render() as one CDNA4
+// (gfx950) kernel family.  Hand-written HIP, wave64, no MFMA (branchy traversal,
+// not a contraction), no CUDA idioms.
+//
+// Replaces, on the device:
+//   render_rows λ   Camera.txt:65-93     rtk_render_kernel (one lane = one pixel of an 8x8 tile = one wave)
+//   get_ray         Camera.txt:177-200   make_primary_ray
+//   ray_color       Camera.txt:203-238   the bounce loop in trace_sample (iterative: radiance = Σ throughput·emission)
+//   world.hit       bvh.h:64-72 &c.      closest_hit: executes the linear traversal program (rtk_device_layout.h)
+//   *.hit           sphere.h:32-58, quad.h:29-73, triangle.h:65-122, constant_medium.h:20-53
+//   scatter/emitted material.h           shade
+//   texture::value  texture.h, perlin.h  texture_value, perlin_noise
+//
+// Parity rules kept in this file (the CPU oracle is compared bit-for-bit where the
+// maths allows): same operation order as the reference inside every formula,
+// v/t computed as (1/t)*v (vec3.h:91-93), no FMA contraction (the file is built
+// with -ffp-contract=off), RNG draws in the reference's order including g++'s
+// right-to-left argument evaluation, and the reference's visiting order in the
+// BVH (left then right, both always).  The hit record is DEFERRED: traversal
+// keeps only (t, winning op); position, normal and uv are computed once per
+// segment from the winning primitive, which gives the same values because they
+// are pure functions of (ray, t, primitive).
+#include <hip/hip_runtime.h>
+
+#include "rtk.h"
+#include "rtk_device_layout.h"
+#include "rtk_trace.h"
+
+namespace rtk {
+
+// ------------------------------------------------------------------ math -----
+template <typename real>
+struct V3 {
+    real x, y, z;
+};
+#define RTK_DEV __device__ __forceinline__
+
+template <typename real> RTK_DEV V3<real> mk(real a, real b, real c) { return V3<real>{a, b, c}; }
+template <typename real> RTK_DEV V3<real> ld3(const real* p) { return V3<real>{p[0], p[1], p[2]}; }
+template <typename real> RTK_DEV V3<real> operator-(V3<real> a) { return V3<real>{-a.x, -a.y, -a.z}; }
+template <typename real> RTK_DEV V3<real> operator+(V3<real> a, V3<real> b) { return V3<real>{a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename real> RTK_DEV V3<real> operator-(V3<real> a, V3<real> b) { return V3<real>{a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename real> RTK_DEV V3<real> operator*(V3<real> a, V3<real> b) { return V3<real>{a.x * b.x, a.y * b.y, a.z * b.z}; }
+template <typename real> RTK_DEV V3<real> scale(real t, V3<real> a) { return V3<real>{t * a.x, t * a.y, t * a.z}; }
+template <typename real> RTK_DEV V3<real> divide(V3<real> a, real t) { return scale(real(1) / t, a); }  // vec3.h:91-93
+template <typename real> RTK_DEV real dot(V3<real> a, V3<real> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename real> RTK_DEV V3<real> cross(V3<real> a, V3<real> b) {
+    return V3<real>{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <typename real> RTK_DEV real length_squared(V3<real> a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+
+RTK_DEV double rt_sqrt(double x) { return __builtin_sqrt(x); }
+RTK_DEV float rt_sqrt(float x) { return __builtin_sqrtf(x); }
+RTK_DEV double rt_fabs(double x) { return __builtin_fabs(x); }
+RTK_DEV float rt_fabs(float x) { return __builtin_fabsf(x); }
+RTK_DEV double rt_fmin(double a, double b) { return __builtin_fmin(a, b); }
+RTK_DEV float rt_fmin(float a, float b) { return __builtin_fminf(a, b); }
+RTK_DEV double rt_fmax(double a, double b) { return __builtin_fmax(a, b); }
+RTK_DEV float rt_fmax(float a, float b) { return __builtin_fmaxf(a, b); }
+RTK_DEV double rt_floor(double x) { return __builtin_floor(x); }
+RTK_DEV float rt_floor(float x) { return __builtin_floorf(x); }
+RTK_DEV double rt_round(double x) { return __builtin_round(x); }
+RTK_DEV float rt_round(float x) { return __builtin_roundf(x); }
+RTK_DEV double rt_pow(double x, double y) { return pow(x, y); }
+RTK_DEV float rt_pow(float x, float y) { return powf(x, y); }
+RTK_DEV double rt_log(double x) { return log(x); }
+RTK_DEV float rt_log(float x) { return logf(x); }
+RTK_DEV double rt_sin(double x) { return sin(x); }
+RTK_DEV float rt_sin(float x) { return sinf(x); }
+RTK_DEV double rt_acos(double x) { return acos(x); }
+RTK_DEV float rt_acos(float x) { return acosf(x); }
+RTK_DEV double rt_atan2(double y, double x) { return atan2(y, x); }
+RTK_DEV float rt_atan2(float y, float x) { return atan2f(y, x); }
+
+template <typename real> RTK_DEV real real_inf() { return real(__builtin_huge_val()); }
+template <typename real> RTK_DEV V3<real> unit_vector(V3<real> a) { return divide(a, rt_sqrt(length_squared(a))); }
+template <typename real> RTK_DEV bool near_zero(V3<real> a) {
+    const real s = real(1e-8);
+    return rt_fabs(a.x) < s && rt_fabs(a.y) < s && rt_fabs(a.z) < s;
+}
+template <typename real> RTK_DEV V3<real> reflect(V3<real> v, V3<real> n) { return v - scale(real(2) * dot(v, n), n); }  // vec3.h:125-127
+template <typename real> RTK_DEV V3<real> refract(V3<real> uv, V3<real> n, real eta) {                                  // vec3.h:128-133
+    real cos_theta = rt_fmin(dot(-uv, n), real(1));
+    V3<real> perp = scale(eta, uv + scale(cos_theta, n));
+    V3<real> par = scale(-rt_sqrt(rt_fabs(real(1) - length_squared(perp))), n);
+    return perp + par;
+}
+
+// ------------------------------------------------------------------ counters --
+template <bool COUNT>
+struct Counters {
+    uint32_t c[C_COUNT];
+    RTK_DEV void clear() {
+#pragma unroll
+        for (int k = 0; k < C_COUNT; k++) c[k] = 0;
+    }
+    RTK_DEV void inc(int slot, uint32_t n = 1) { c[slot] += n; }
+};
+template <>
+struct Counters<false> {
+    RTK_DEV void clear() {}
+    RTK_DEV void inc(int, uint32_t = 1) {}
+};
+
+// ------------------------------------------------------------------ RNG -------
+// Per-lane PCG-RXS-M-XS-32: 32-bit state, one v_mul_lo_u32 for the LCG step and
+// one for the output permutation, no 64-bit multiply (gfx950 has no fast one).
+// The stream of a sample is seeded by hashing (seed, sample, pixel), so it does
+// not depend on lane, tile, launch geometry or GPU count.
+RTK_DEV uint32_t pcg_hash(uint32_t v) {
+    uint32_t st = v * 747796405u + 2891336453u;
+    uint32_t w = ((st >> ((st >> 28u) + 4u)) ^ st) * 277803737u;
+    return (w >> 22u) ^ w;
+}
+template <typename real, bool COUNT>
+RTK_DEV real rnd(uint32_t& s, Counters<COUNT>& cnt) {
+    uint32_t old = s;
+    s = old * 747796405u + 2891336453u;
+    uint32_t w = ((old >> ((old >> 28u) + 4u)) ^ old) * 277803737u;
+    cnt.inc(C_RNG);
+    return real(((w >> 22u) ^ w) >> 8) * real(1.0 / 16777216.0);
+}
+// vec3.h:107-115 -- always accepts; components drawn z, y, x.
+template <typename real, bool COUNT>
+RTK_DEV V3<real> random_unit_vector(uint32_t& s, Counters<COUNT>& cnt) {
+    real c = real(-1) + real(2) * rnd<real>(s, cnt);
+    real b = real(-1) + real(2) * rnd<real>(s, cnt);
+    real a = real(-1) + real(2) * rnd<real>(s, cnt);
+    V3<real> p = mk(a, b, c);
+    return divide(p, rt_sqrt(length_squared(p)));
+}
+
+// ------------------------------------------------------------------ rays ------
+// Object-space ray for a chain of instance transforms (hittable.h:46-49,101-116).
+template <typename real>
+RTK_DEV void apply_chain(const ChainRec<real>* __restrict__ chains, uint32_t chain, V3<real> wo, V3<real> wd, V3<real>& o, V3<real>& d) {
+    o = wo;
+    d = wd;
+    if (chain == 0) return;
+    const ChainRec<real>& ch = chains[chain];
+    const int n = ch.count;
+    for (int k = 0; k < n; k++) {
+        if (ch.is_rotate[k]) {
+            const real s = ch.a[k], c = ch.b[k];
+            o = mk((c * o.x) - (s * o.z), o.y, (s * o.x) + (c * o.z));
+            d = mk((c * d.x) - (s * d.z), d.y, (s * d.x) + (c * d.z));
+        } else {
+            o = o - mk(ch.a[k], ch.b[k], ch.c[k]);
+        }
+    }
+}
+// Hit point and normal back to world space (hittable.h:55,122-134), innermost first.
+template <typename real>
+RTK_DEV void unapply_chain(const ChainRec<real>* __restrict__ chains, uint32_t chain, V3<real>& p, V3<real>& n) {
+    if (chain == 0) return;
+    const ChainRec<real>& ch = chains[chain];
+    for (int k = ch.count - 1; k >= 0; k--) {
+        if (ch.is_rotate[k]) {
+            const real s = ch.a[k], c = ch.b[k];
+            p = mk((c * p.x) + (s * p.z), p.y, (-s * p.x) + (c * p.z));
+            n = mk((c * n.x) + (s * n.z), n.y, (-s * n.x) + (c * n.z));
+        } else {
+            p = p + mk(ch.a[k], ch.b[k], ch.c[k]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ traversal --
+// aabb::hit (aabb.h:61-85).  The reference's per-axis early-outs reduce to one
+// final comparison because tmin only grows and tmax only shrinks; NaNs from
+// 0*inf are handled exactly as its `<`/`>` comparisons handle them (the select
+// keeps the reference's else-branch, fmax/fmin drop a NaN operand).
+template <typename real>
+RTK_DEV bool slab_test(const BoxRec<real>& b, V3<real> o, V3<real> inv, real tmin, real tmax) {
+    {
+        real t0 = (b.xmin - o.x) * inv.x, t1 = (b.xmax - o.x) * inv.x;
+        bool lt = t0 < t1;
+        real nr = lt ? t0 : t1, fr = lt ? t1 : t0;
+        tmin = rt_fmax(nr, tmin);
+        tmax = rt_fmin(fr, tmax);
+    }
+    {
+        real t0 = (b.ymin - o.y) * inv.y, t1 = (b.ymax - o.y) * inv.y;
+        bool lt = t0 < t1;
+        real nr = lt ? t0 : t1, fr = lt ? t1 : t0;
+        tmin = rt_fmax(nr, tmin);
+        tmax = rt_fmin(fr, tmax);
+    }
+    {
+        real t0 = (b.zmin - o.z) * inv.z, t1 = (b.zmax - o.z) * inv.z;
+        bool lt = t0 < t1;
+        real nr = lt ? t0 : t1, fr = lt ? t1 : t0;
+        tmin = rt_fmax(nr, tmin);
+        tmax = rt_fmin(fr, tmax);
+    }
+    return tmax > tmin;
+}
+
+// sphere::hit up to the accepted root (sphere.h:32-49).
+template <typename real>
+RTK_DEV bool sphere_root(const SphereRec<real>& s, V3<real> o, V3<real> d, real a, real tm, real tmin, real tmax, real& root) {
+    V3<real> cc = mk(s.cx, s.cy, s.cz) + scale(tm, mk(s.dx, s.dy, s.dz));
+    V3<real> oc = cc - o;
+    real h = dot(d, oc);
+    real c = length_squared(oc) - s.radius * s.radius;
+    real disc = h * h - a * c;
+    if (disc < real(0)) return false;
+    real sq = rt_sqrt(disc);
+    real r = (h - sq) / a;
+    if (!(tmin < r && r < tmax)) {
+        r = (h + sq) / a;
+        if (!(tmin < r && r < tmax)) return false;
+    }
+    root = r;
+    return true;
+}
+
+// quad::hit (quad.h:29-73); alpha/beta returned for the deferred uv.
+template <typename real>
+RTK_DEV bool quad_test(const QuadRec<real>& q, V3<real> o, V3<real> d, real tmin, real tmax, real& t_out, real& alpha, real& beta) {
+    V3<real> n = ld3(q.n);
+    real denom = dot(n, d);
+    if (rt_fabs(denom) < real(1e-8)) return false;
+    real t = (q.D - dot(n, o)) / denom;
+    if (!(tmin <= t && t <= tmax)) return false;
+    V3<real> P = o + scale(t, d);
+    V3<real> planar = P - ld3(q.Q);
+    alpha = dot(ld3(q.w), cross(planar, ld3(q.v)));
+    beta = dot(ld3(q.w), cross(ld3(q.u), planar));
+    if (!(real(0) <= alpha && alpha <= real(1)) || !(real(0) <= beta && beta <= real(1))) return false;
+    t_out = t;
+    return true;
+}
+
+// triangle::hit (triangle.h:65-122): Moeller-Trumbore with the reference's float
+// determinant (triangle.h:72,77) and float barycentrics (triangle.h:96-98).
+template <typename real>
+RTK_DEV bool tri_test(const TriRec<real>& tr, V3<real> o, V3<real> d, real tmin, real tmax, real& t_out, float& fa, float& fb, float& fg) {
+    V3<real> e1 = ld3(tr.e1), e2 = ld3(tr.e2);
+    V3<real> pvec = cross(d, e2);
+    float det = float(dot(e1, pvec));
+    if (__builtin_fabsf(det) < real(1e-8)) return false;
+    float inv_det = 1.0f / det;
+    V3<real> tvec = o - ld3(tr.p0);
+    real u = dot(tvec, pvec) * real(inv_det);
+    if (u < real(0) || u > real(1)) return false;
+    V3<real> qvec = cross(tvec, e1);
+    real v = dot(d, qvec) * real(inv_det);
+    if (v < real(0) || u + v > real(1)) return false;
+    real t = dot(e2, qvec) * real(inv_det);
+    if (t < tmin || t > tmax) return false;
+    fa = float(real(1) - u - v);
+    fb = float(u);
+    fg = float(v);
+    real da = real(fa), db = real(fb);
+    if (!(real(0) <= da && da <= real(1)) || !(real(0) <= db && db <= real(1))) return false;
+    t_out = t;
+    return true;
+}
+
+// world.hit(r, interval(0.001, inf), rec) (Camera.txt:211): run the traversal
+// program.  Returns the closest t and the op that produced it (kNoHit: miss).
+template <typename real, uint32_t FEAT, bool COUNT>
+RTK_DEV void closest_hit(const SceneView<real>& sc, V3<real> wo, V3<real> wd, real tm, uint32_t& rng, Counters<COUNT>& cnt, real& best_t_out,
+                         uint32_t& best_pc_out) {
+    V3<real> o = wo, d = wd;
+    V3<real> inv = mk(real(1) / d.x, real(1) / d.y, real(1) / d.z);  // aabb.h:67, hoisted: same value per box
+    real a = length_squared(d);                                      // sphere.h:35, hoisted likewise
+    real tmin = real(0.001), best_t = real_inf<real>();
+    uint32_t best_pc = kNoHit;
+    // constant_medium::hit nests two closest-hit queries of its boundary
+    // (constant_medium.h:23,26); the outer query state is parked here meanwhile.
+    real sv_tmin = 0, sv_best_t = 0, rec1_t = 0;
+    uint32_t sv_best_pc = kNoHit;
+
+    uint32_t pc = 0;
+    for (;;) {
+        const Op op = sc.ops[pc];
+        const uint32_t kind = op.kind_payload & 15u;
+        const uint32_t idx = op.kind_payload >> 4;
+        if (kind == OP_BOX) {
+            cnt.inc(C_BOX);
+            const bool hit = slab_test(sc.boxes[idx], o, inv, tmin, best_t);
+            pc = hit ? pc + 1 : op.aux;
+            continue;
+        }
+        if (kind == OP_END) break;
+        if (kind == OP_SPHERE) {
+            cnt.inc(C_SPHERE);
+            real r;
+            if (sphere_root(sc.spheres[idx], o, d, a, tm, tmin, best_t, r)) {
+                best_t = r;
+                best_pc = pc;
+            }
+        } else if ((FEAT & F_QUAD) && kind == OP_QUAD) {
+            cnt.inc(C_QUAD);
+            real t, al, be;
+            if (quad_test(sc.quads[idx], o, d, tmin, best_t, t, al, be)) {
+                best_t = t;
+                best_pc = pc;
+            }
+        } else if ((FEAT & F_TRI) && kind == OP_TRI) {
+            cnt.inc(C_TRI);
+            real t;
+            float fa, fb, fg;
+            if (tri_test(sc.tris[idx], o, d, tmin, best_t, t, fa, fb, fg)) {
+                best_t = t;
+                best_pc = pc;
+            }
+        } else if ((FEAT & F_XFORM) && kind == OP_CHAIN) {
+            cnt.inc(C_XFORM, op.aux);
+            apply_chain(sc.chains, idx, wo, wd, o, d);
+            inv = mk(real(1) / d.x, real(1) / d.y, real(1) / d.z);
+            a = length_squared(d);
+        } else if ((FEAT & F_MEDIA) && kind == OP_MED_BEGIN) {
+            cnt.inc(C_MEDIUM);
+            sv_tmin = tmin;
+            sv_best_t = best_t;
+            sv_best_pc = best_pc;
+            tmin = -real_inf<real>();
+            best_t = real_inf<real>();
+            best_pc = kNoHit;
+        } else if ((FEAT & F_MEDIA) && kind == OP_MED_MID) {
+            if (best_pc == kNoHit) {  // constant_medium.h:23-24
+                tmin = sv_tmin;
+                best_t = sv_best_t;
+                best_pc = sv_best_pc;
+                pc = op.aux;
+                continue;
+            }
+            rec1_t = best_t;
+            tmin = rec1_t + real(0.0001);  // constant_medium.h:26
+            best_t = real_inf<real>();
+            best_pc = kNoHit;
+        } else if ((FEAT & F_MEDIA) && kind == OP_MED_END) {
+            const bool hit2 = best_pc != kNoHit;
+            real r2 = best_t;
+            tmin = sv_tmin;
+            best_t = sv_best_t;
+            best_pc = sv_best_pc;
+            if (hit2) {  // constant_medium.h:29-50
+                real r1 = rec1_t;
+                if (r1 < tmin) r1 = tmin;
+                if (r2 > best_t) r2 = best_t;
+                if (r1 < r2) {
+                    if (r1 < real(0)) r1 = real(0);
+                    const real ray_length = rt_sqrt(a);
+                    const real inside = (r2 - r1) * ray_length;
+                    const real hit_distance = sc.media[idx].neg_inv_density * rt_log(rnd<real>(rng, cnt));
+                    if (!(hit_distance > inside)) {
+                        best_t = r1 + hit_distance / ray_length;
+                        best_pc = pc;
+                    }
+                }
+            }
+        }
+        pc++;
+    }
+    best_t_out = best_t;
+    best_pc_out = best_pc;
+}
+
+// ------------------------------------------------------------------ textures --
+// perlin::noise (perlin.h:14-37,72-89).
+template <typename real, bool COUNT>
+RTK_DEV real perlin_noise(const PerlinRec<real>& pn, V3<real> p, Counters<COUNT>& cnt) {
+    cnt.inc(C_NOISE);
+    const real fx = rt_floor(p.x), fy = rt_floor(p.y), fz = rt_floor(p.z);
+    const real u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    const int i = int(fx), j = int(fy), k = int(fz);
+    const real uu = u * u * (real(3) - real(2) * u);
+    const real vv = v * v * (real(3) - real(2) * v);
+    const real ww = w * w * (real(3) - real(2) * w);
+    real accum = real(0);
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const int idx = pn.perm_x[(i + a) & 255] ^ pn.perm_y[(j + b) & 255] ^ pn.perm_z[(k + c) & 255];
+                const V3<real> g = ld3(pn.randvec[idx]);
+                const V3<real> wv = mk(u - real(a), v - real(b), w - real(c));
+                accum += (real(a) * uu + real(1 - a) * (real(1) - uu)) * (real(b) * vv + real(1 - b) * (real(1) - vv)) *
+                         (real(c) * ww + real(1 - c) * (real(1) - ww)) * dot(g, wv);
+            }
+    return accum;
+}
+
+// texture::value (texture.h:20-120); checker nesting is followed iteratively.
+template <typename real, bool COUNT>
+RTK_DEV V3<real> texture_value(const SceneView<real>& sc, int tex, real u, real v, V3<real> p, Counters<COUNT>& cnt) {
+    for (;;) {
+        const TextureRec<real>& t = sc.textures[tex];
+        if (t.kind == RTK_TEX_SOLID) return ld3(t.color);
+        if (t.kind == RTK_TEX_CHECKER) {  // texture.h:42-50
+            const int xi = int(rt_floor(t.param * p.x));
+            const int yi = int(rt_floor(t.param * p.y));
+            const int zi = int(rt_floor(t.param * p.z));
+            tex = ((xi + yi + zi) % 2 == 0) ? t.even : t.odd;
+            continue;
+        }
+        if (t.kind == RTK_TEX_CHECKER_TRI) {  // texture.h:66-76
+            v = real(1) - v;
+            const int ui = int(rt_round(t.param * u * real(10)));
+            const int vi = int(rt_round(t.param * v * real(10)));
+            tex = ((ui + vi) % 2 == 0) ? t.even : t.odd;
+            continue;
+        }
+        if (t.kind == RTK_TEX_IMAGE) {  // texture.h:90-104, rtw_stb_image.h:71-81
+            const ImageRec im = sc.images[t.image];
+            if (im.width <= 0 || im.height <= 0) return mk(real(0), real(1), real(1));
+            u = u < real(0) ? real(0) : (u > real(1) ? real(1) : u);
+            const real vc = v < real(0) ? real(0) : (v > real(1) ? real(1) : v);
+            v = real(1) - vc;
+            int i = int(u * real(im.width));
+            int j = int(v * real(im.height));
+            i = i < 0 ? 0 : (i < im.width ? i : im.width - 1);
+            j = j < 0 ? 0 : (j < im.height ? j : im.height - 1);
+            cnt.inc(C_TEXEL);
+            const uint8_t* px = sc.texels + im.texel_offset + (int64_t(j) * im.width + i) * 3;
+            const real cs = real(1) / real(255);
+            return mk(cs * real(px[0]), cs * real(px[1]), cs * real(px[2]));
+        }
+        // noise_texture (texture.h:114-116) with perlin::turb(p, 7) (perlin.h:38-50)
+        const PerlinRec<real>& pn = sc.perlins[t.image];
+        real accum = real(0), weight = real(1);
+        V3<real> q = p;
+        for (int k = 0; k < 7; k++) {
+            accum += weight * perlin_noise(pn, q, cnt);
+            weight *= real(0.5);
+            q = mk(q.x * real(2), q.y * real(2), q.z * real(2));
+        }
+        const real s = real(1) + rt_sin(t.param * p.z + real(10) * rt_fabs(accum));
+        return mk(s * real(0.5), s * real(0.5), s * real(0.5));
+    }
+}
+
+template <typename real, uint32_t FEAT, bool COUNT>
+RTK_DEV V3<real> material_color(const SceneView<real>& sc, const MaterialRec<real>& m, real u, real v, V3<real> p, Counters<COUNT>& cnt) {
+    if (!(FEAT & F_TEXTURE) || m.tex < 0) return ld3(m.albedo);  // solid colours are folded into the material at upload
+    return texture_value(sc, m.tex, u, v, p, cnt);
+}
+
+// ------------------------------------------------------------------ shading ---
+template <typename real>
+struct Surface {  // hit_record (hittable.h:11-27)
+    V3<real> p, normal;
+    real u, v;
+    int material;
+    bool front_face;
+};
+
+// Build the hit record of the winning op (the deferred half of *.hit).
+template <typename real, uint32_t FEAT>
+RTK_DEV void make_surface(const SceneView<real>& sc, uint32_t best_pc, real t, V3<real> wo, V3<real> wd, real tm, Surface<real>& sf) {
+    const Op op = sc.ops[best_pc];
+    const uint32_t kind = op.kind_payload & 15u;
+    const uint32_t idx = op.kind_payload >> 4;
+    const uint32_t chain = (FEAT & F_XFORM) ? op.aux : 0u;
+    V3<real> o = wo, d = wd;
+    if (FEAT & F_XFORM) apply_chain(sc.chains, chain, wo, wd, o, d);
+    sf.p = o + scale(t, d);
+    sf.u = real(0);
+    sf.v = real(0);
+    V3<real> outward;
+    bool face_from_ray = true;
+    if (kind == OP_SPHERE) {  // sphere.h:50-56,67-73
+        const SphereRec<real>& s = sc.spheres[idx];
+        V3<real> cc = mk(s.cx, s.cy, s.cz) + scale(tm, mk(s.dx, s.dy, s.dz));
+        outward = divide(sf.p - cc, s.radius);
+        sf.material = s.material;
+        if ((FEAT & F_TEXTURE) && sc.materials[s.material].needs_uv) {
+            const real pi = real(3.1415926535897932385);
+            real theta = rt_acos(-outward.y);
+            real phi = rt_atan2(-outward.z, outward.x) + pi;
+            sf.u = phi / (real(2) * pi);
+            sf.v = theta / pi;
+        }
+    } else if ((FEAT & F_QUAD) && kind == OP_QUAD) {  // quad.h:44-57
+        const QuadRec<real>& q = sc.quads[idx];
+        V3<real> planar = sf.p - ld3(q.Q);
+        sf.u = dot(ld3(q.w), cross(planar, ld3(q.v)));
+        sf.v = dot(ld3(q.w), cross(ld3(q.u), planar));
+        outward = ld3(q.n);
+        sf.material = q.material;
+    } else if ((FEAT & F_TRI) && kind == OP_TRI) {  // triangle.h:96-110
+        const TriRec<real>& tr = sc.tris[idx];
+        real tt;
+        float fa = 0, fb = 0, fg = 0;
+        tri_test(tr, o, d, -real_inf<real>(), real_inf<real>(), tt, fa, fb, fg);
+        sf.u = real(fa * tr.uv0[0] + fb * tr.uv1[0] + fg * tr.uv2[0]);
+        sf.v = real(fa * tr.uv0[1] + fb * tr.uv1[1] + fg * tr.uv2[1]);
+        outward = ld3(tr.n);
+        sf.material = tr.material;
+    } else {  // OP_MED_END: constant_medium.h:45-50
+        outward = mk(real(1), real(0), real(0));
+        sf.material = sc.media[idx].material;
+        face_from_ray = false;
+    }
+    if (face_from_ray) {  // hittable.h:23-26
+        sf.front_face = dot(d, outward) < real(0);
+        sf.normal = sf.front_face ? outward : -outward;
+    } else {
+        sf.front_face = true;
+        sf.normal = outward;
+    }
+    if (FEAT & F_XFORM) unapply_chain(sc.chains, chain, sf.p, sf.normal);
+}
+
+// get_lighting (Camera.txt:240-272).
+template <typename real>
+RTK_DEV V3<real> point_lighting(const SceneView<real>& sc, V3<real> p, V3<real> normal) {
+    V3<real> result = mk(real(0), real(0), real(0));
+    for (int i = 0; i < sc.n_lights; i++) {
+        const LightRec<real>& L = sc.lights[i];
+        V3<real> dir = ld3(L.position) - p;
+        real dist2 = length_squared(dir);
+        dir = unit_vector(dir);
+        real dn = dot(normal, dir);
+        real diffuse = dn > real(0) ? dn : real(0);
+        real radius_effect = L.size * real(0.1);
+        if (dist2 <= L.size * L.size) {
+            result = result + scale(diffuse, ld3(L.intensity));
+        } else {
+            real att = real(1) / (dist2 + radius_effect);
+            result = result + scale(diffuse, scale(att, ld3(L.intensity)));
+        }
+    }
+    return result;
+}
+
+// One sample: get_ray + ray_color (Camera.txt:177-238), iteratively.
+template <typename real, uint32_t FEAT, bool COUNT>
+RTK_DEV V3<real> trace_sample(const SceneView<real>& sc, const CameraRec<real>& cam, int i, int j, uint32_t& rng, Counters<COUNT>& cnt) {
+    // --- get_ray: sample_square draws y then x (g++ order), then the lens, then time
+    const real oy = rnd<real>(rng, cnt) - real(0.5);
+    const real ox = rnd<real>(rng, cnt) - real(0.5);
+    const V3<real> pixel_sample = ld3(cam.pixel00) + scale(real(i) + ox, ld3(cam.du)) + scale(real(j) + oy, ld3(cam.dv));
+    V3<real> ro = ld3(cam.center);
+    if (cam.defocus_angle > real(0)) {  // vec3.h:135-142
+        real px, py;
+        for (;;) {
+            py = real(-1) + real(2) * rnd<real>(rng, cnt);
+            px = real(-1) + real(2) * rnd<real>(rng, cnt);
+            if (px * px + py * py + real(0) * real(0) < real(1)) break;
+        }
+        ro = ld3(cam.center) + scale(px, ld3(cam.disk_u)) + scale(py, ld3(cam.disk_v));
+    }
+    V3<real> rd = pixel_sample - ro;
+    const real tm = rnd<real>(rng, cnt);
+
+    // --- ray_color
+    V3<real> radiance = mk(real(0), real(0), real(0));
+    V3<real> throughput = mk(real(1), real(1), real(1));
+    for (int depth = cam.max_depth; depth > 0; depth--) {
+        cnt.inc(C_SEGMENTS);
+        real t;
+        uint32_t best_pc;
+        closest_hit<real, FEAT, COUNT>(sc, ro, rd, tm, rng, cnt, t, best_pc);
+        if (best_pc == kNoHit) {  // Camera.txt:211-213
+            radiance = radiance + throughput * ld3(cam.background);
+            break;
+        }
+        cnt.inc(C_SURFACE);
+        Surface<real> sf;
+        make_surface<real, FEAT>(sc, best_pc, t, ro, rd, tm, sf);
+        const MaterialRec<real>& m = sc.materials[sf.material];
+
+        V3<real> attenuation, next_d;
+        bool scattered = true;
+        if (m.kind == RTK_MAT_LAMBERTIAN) {  // material.h:29-38
+            V3<real> dir = sf.normal + random_unit_vector<real>(rng, cnt);
+            if (near_zero(dir)) dir = sf.normal;
+            next_d = dir;
+            attenuation = material_color<real, FEAT>(sc, m, sf.u, sf.v, sf.p, cnt);
+        } else if (m.kind == RTK_MAT_METAL) {  // material.h:82-88
+            V3<real> refl = reflect(rd, sf.normal);
+            V3<real> fuzz = scale(m.param, random_unit_vector<real>(rng, cnt));
+            next_d = unit_vector(refl) + fuzz;
+            attenuation = ld3(m.albedo);
+            scattered = dot(next_d, sf.normal) > real(0);
+        } else if (m.kind == RTK_MAT_DIELECTRIC) {  // material.h:47-65
+            attenuation = mk(real(1), real(1), real(1));
+            const real ri = sf.front_face ? (real(1) / m.param) : m.param;
+            const V3<real> unit_d = unit_vector(rd);
+            const real cos_theta = rt_fmin(dot(-unit_d, sf.normal), real(1));
+            const real sin_theta = rt_sqrt(real(1) - cos_theta * cos_theta);
+            bool reflect_it = ri * sin_theta > real(1);
+            if (!reflect_it) {  // Schlick (material.h:69-74); the draw is skipped on total internal reflection
+                real r0 = (real(1) - ri) / (real(1) + ri);
+                r0 = r0 * r0;
+                const real refl = r0 + (real(1) - r0) * rt_pow(real(1) - cos_theta, real(5));
+                reflect_it = refl > rnd<real>(rng, cnt);
+            }
+            next_d = reflect_it ? reflect(unit_d, sf.normal) : refract(unit_d, sf.normal, ri);
+        } else if ((FEAT & F_EXOTIC_MAT) && m.kind == RTK_MAT_ISOTROPIC) {  // material.h:129-134
+            next_d = random_unit_vector<real>(rng, cnt);
+            attenuation = material_color<real, FEAT>(sc, m, sf.u, sf.v, sf.p, cnt);
+        } else if ((FEAT & F_EXOTIC_MAT) && m.kind == RTK_MAT_SPECULAR) {  // material.h:145-167
+            const V3<real> unit_d = unit_vector(rd);
+            const V3<real> refl = reflect(unit_d, sf.normal);
+            V3<real> diffuse = random_unit_vector<real>(rng, cnt);  // random_on_hemisphere, vec3.h:116-124
+            if (!(dot(diffuse, sf.normal) > real(0))) diffuse = -diffuse;
+            const real f = rt_pow(real(1) - dot(refl, unit_d), m.param);
+            V3<real> dir = scale(f, refl) + scale(real(1) - f, diffuse);
+            if (near_zero(dir)) dir = sf.normal;
+            next_d = dir;
+            attenuation = ld3(m.albedo);
+        } else {  // diffuse_light / emissive_light: emits, never scatters (material.h:99-101,116-118)
+            if (FEAT & F_EXOTIC_MAT) {
+                V3<real> emitted = material_color<real, FEAT>(sc, m, sf.u, sf.v, sf.p, cnt);
+                radiance = radiance + throughput * emitted;
+            }
+            break;
+        }
+        if (!scattered) break;  // Camera.txt:223-225 (emission of a scattering material is zero)
+        if ((FEAT & F_LIGHTS) && sc.n_lights > 0) {  // Camera.txt:228
+            V3<real> lighting = attenuation * point_lighting(sc, sf.p, sf.normal);
+            radiance = radiance + throughput * lighting;
+        }
+        throughput = throughput * attenuation;
+        ro = sf.p;
+        rd = next_d;
+    }
+    return radiance;
+}
+
+RTK_DEV uint8_t to_byte(double x) {  // Camera.txt:29-34,77-83
+    double g = x > 0 ? __builtin_sqrt(x) : 0.0;
+    g = g < 0.000 ? 0.000 : (g > 0.999 ? 0.999 : g);
+    return uint8_t(int(255.999 * g));
+}
+
+// ------------------------------------------------------------------ kernel ----
+// One wave = one 8x8 tile; lane l owns pixel (l & 7, l >> 3) of the tile and
+// walks its samples in order, so the per-pixel sum has the reference's
+// summation order (Camera.txt:70-73).
+template <typename real, uint32_t FEAT, bool COUNT>
+__global__ __launch_bounds__(256) void rtk_render_kernel(SceneView<real> sc, CameraRec<real> cam, TileMap tmap, uint32_t seed, real* __restrict__ out_linear,
+                                                          uint8_t* __restrict__ out_rgb8, unsigned long long* __restrict__ counters) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int local_tile = blockIdx.x * 4 + wave;
+    const int tile = local_tile * tmap.n_ranks + tmap.rank;
+    const bool tile_ok = local_tile < tmap.n_tiles_local && tile < tmap.tiles_x * tmap.tiles_y;
+    const int tx = tile_ok ? tile % tmap.tiles_x : 0, ty = tile_ok ? tile / tmap.tiles_x : 0;
+    const int i = tx * 8 + (lane & 7), j = ty * 8 + (lane >> 3);
+    const bool active = tile_ok && i < cam.width && j < cam.height;
+
+    Counters<COUNT> cnt;
+    cnt.clear();
+    V3<real> sum = mk(real(0), real(0), real(0));
+    if (active) {
+        const uint32_t pixel = uint32_t(j * cam.width + i);
+        const uint32_t seed_hash = pcg_hash(seed);
+        for (int s = 0; s < cam.spp; s++) {
+            uint32_t rng = pcg_hash(pixel + pcg_hash(uint32_t(s) + seed_hash));
+            cnt.inc(C_SAMPLES);
+            sum = sum + trace_sample<real, FEAT, COUNT>(sc, cam, i, j, rng, cnt);
+        }
+        sum = scale(cam.samples_scale, sum);  // Camera.txt:74
+    }
+    if (tmap.compact) {
+        if (tile_ok && out_linear) {
+            real* base = out_linear + size_t(local_tile) * 192 + lane;
+            base[0] = sum.x;
+            base[64] = sum.y;
+            base[128] = sum.z;
+        }
+    } else if (active) {
+        const size_t idx = (size_t(j) * cam.width + i) * 3;
+        if (out_linear) {
+            out_linear[idx] = sum.x;
+            out_linear[idx + 1] = sum.y;
+            out_linear[idx + 2] = sum.z;
+        }
+        if (out_rgb8) {
+            out_rgb8[idx] = to_byte(double(sum.x));
+            out_rgb8[idx + 1] = to_byte(double(sum.y));
+            out_rgb8[idx + 2] = to_byte(double(sum.z));
+        }
+    }
+    if constexpr (COUNT) {
+#pragma unroll
+        for (int k = 0; k < C_COUNT; k++) {
+            unsigned long long v = cnt.c[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0 && v) atomicAdd(&counters[k], v);
+        }
+    }
+}
+
+// Gathered compact tiles -> row-major image (+ bytes).  One thread per pixel slot.
+template <typename real>
+__global__ __launch_bounds__(256) void rtk_unpermute_kernel(const real* __restrict__ gathered, int width, int height, int tiles_x, int n_tiles, int n_ranks,
+                                                             long long tiles_per_rank, real* __restrict__ out_linear, uint8_t* __restrict__ out_rgb8) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = int(gid & 63);
+    const long long tile = gid >> 6;
+    if (tile >= n_tiles) return;
+    const int i = int(tile % tiles_x) * 8 + (lane & 7), j = int(tile / tiles_x) * 8 + (lane >> 3);
+    if (i >= width || j >= height) return;
+    const long long rank = tile % n_ranks, local_tile = tile / n_ranks;
+    const real* src = gathered + (rank * tiles_per_rank + local_tile) * 192 + lane;
+    const real r = src[0], g = src[64], b = src[128];
+    const size_t idx = (size_t(j) * width + i) * 3;
+    if (out_linear) {
+        out_linear[idx] = r;
+        out_linear[idx + 1] = g;
+        out_linear[idx + 2] = b;
+    }
+    if (out_rgb8) {
+        out_rgb8[idx] = to_byte(double(r));
+        out_rgb8[idx + 1] = to_byte(double(g));
+        out_rgb8[idx + 2] = to_byte(double(b));
+    }
+}
+
+// ------------------------------------------------------------------ launchers --
+template <typename real, uint32_t FEAT, bool COUNT>
+static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>& cam, const TileMap& tmap, uint32_t seed, void* out_linear, uint8_t* out_rgb8,
+                             unsigned long long* counters, hipStream_t stream) {
+    const int blocks = (tmap.n_tiles_local + 3) / 4;
+    if (blocks <= 0) return hipSuccess;
+    rtk_render_kernel<real, FEAT, COUNT><<<dim3(blocks), dim3(256), 0, stream>>>(sc, cam, tmap, seed, static_cast<real*>(out_linear), out_rgb8, counters);
+    return hipGetLastError();
+}
+
+template <typename real>
+hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>& cam, const TileMap& tmap, uint32_t seed, uint32_t features, bool count,
+                         void* out_linear, uint8_t* out_rgb8, unsigned long long* counters, hipStream_t stream) {
+    if (count) return launch_one<real, kFeatAll, true>(sc, cam, tmap, seed, out_linear, out_rgb8, counters, stream);
+    if (features == kFeatLean) return launch_one<real, kFeatLean, false>(sc, cam, tmap, seed, out_linear, out_rgb8, counters, stream);
+    return launch_one<real, kFeatAll, false>(sc, cam, tmap, seed, out_linear, out_rgb8, counters, stream);
+}
+template hipError_t launch_render<double>(const SceneView<double>&, const CameraRec<double>&, const TileMap&, uint32_t, uint32_t, bool, void*, uint8_t*,
+                                          unsigned long long*, hipStream_t);
+template hipError_t launch_render<float>(const SceneView<float>&, const CameraRec<float>&, const TileMap&, uint32_t, uint32_t, bool, void*, uint8_t*,
+                                         unsigned long long*, hipStream_t);
+
+template <typename real>
+hipError_t launch_unpermute(const void* gathered, int width, int height, int n_ranks, long long tiles_per_rank, void* out_linear, uint8_t* out_rgb8,
+                            hipStream_t stream) {
+    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
+    const long long slots = (long long)tiles_x * tiles_y * 64;
+    const int blocks = int((slots + 255) / 256);
+    rtk_unpermute_kernel<real><<<dim3(blocks), dim3(256), 0, stream>>>(static_cast<const real*>(gathered), width, height, tiles_x, tiles_x * tiles_y, n_ranks,
+                                                                       tiles_per_rank, static_cast<real*>(out_linear), out_rgb8);
+    return hipGetLastError();
+}
+template hipError_t launch_unpermute<double>(const void*, int, int, int, long long, void*, uint8_t*, hipStream_t);
+template hipError_t launch_unpermute<float>(const void*, int, int, int, long long, void*, uint8_t*, hipStream_t);
+
+const char* render_kernel_name(bool f64, uint32_t features, bool count) {
+    if (count) return f64 ? "rtk_render_kernel<double, 127u, true>" : "rtk_render_kernel<float, 127u, true>";
+    if (features == kFeatLean) return f64 ? "rtk_render_kernel<double, 0u, false>" : "rtk_render_kernel<float, 0u, false>";
+    return f64 ? "rtk_render_kernel<double, 127u, false>" : "rtk_render_kernel<float, 127u, false>";
+}
+
+}  // namespace rtk

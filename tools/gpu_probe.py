@@ -1,0 +1,26 @@
+"""Developer probe: GPU kernel vs CPU oracle on every scene at small sizes (prints a table)."""
+import os, sys, time, tempfile
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import raytracingoneweekendapplication_amd as rt
+from oracle import orc
+
+tmp = tempfile.mkdtemp()
+earth = rt.write_synthetic_earth(os.path.join(tmp, "earth_synth.ppm"), 64, 32)
+cases = [("three_spheres", 64, 36, 8, 10), ("book1_final", 64, 36, 4, 50), ("cornell_box", 40, 40, 8, 25), ("mesh", 64, 36, 4, 10),
+         ("book2_final", 64, 36, 4, 10), ("material_zoo", 96, 54, 8, 12), ("cornell_smoke", 48, 48, 8, 10), ("single_fog", 48, 32, 16, 8)]
+r = rt.Renderer(0)
+for name, W, H, spp, depth in cases:
+    sc = rt.Scene.build(name, image_file=earth)
+    cam = sc.camera(W, H, spp, depth)
+    r.upload(sc)
+    ref, ref8, oc = orc.render(sc.desc_ptr, cam, 1, 8)
+    for mode, label in ((rt.RTK_REAL_F64, "f64"), (rt.RTK_REAL_F32, "f32")):
+        t0 = time.time()
+        g, g8, gc = r.render_host(cam, real_mode=mode, count=True)
+        g2, g28, _ = r.render_host(cam, real_mode=mode, count=False)
+        dt = time.time() - t0
+        d = g - ref
+        bad = {k: (gc[k], oc[k]) for k in gc if gc[k] != oc[k]}
+        print(f"{name:14s} {label} rmse {np.sqrt((d**2).mean()):.3e} max {np.abs(d).max():.3e} u8diff {(g8 != ref8).sum():5d} "
+              f"count-vs-nocount max {np.abs(g - g2).max():.1e} counters {'EQUAL' if not bad else bad} info {r.scene_info()} {dt:.2f}s", flush=True)

@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline measurement: Msamples/s of the camera::render() sample
+loop on the RTIOW book-1 final scene, 1920x1080x100 spp, depth 50 (BASELINE.json
+configs[1]), on N MI355X GPUs of one node.
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full render of the image: every rank renders its interleaved 8x8
+tiles (no collective while rendering), then ONE gather of the compact tile buffers
+to rank 0 over RCCL/xGMI and the un-permute kernel there.  Inputs (scene, camera)
+are resident in HBM before the timed region; the framebuffer stays on the device.
+value = W*H*spp*K / max-over-ranks(time) / 1e6, whole job.  Total work is fixed as
+N grows, so scaling is "strong".
+
+The headline dtype is f64: the reference computes in double (vec3.h:7) and the
+parity bar (RMSE < 1e-4 against the CPU at matched seed) is only meaningful at
+that precision.  The f32 kernel's rate is reported beside it under
+"f32_mode" -- never as `value`.
+
+Extra objects on the JSON line:
+  roofline      HBM-bandwidth roofline of the render kernel: algorithmic bytes per
+                launch (SURVEY.md 8(d) byte model x exact work counters from the
+                counting kernel) / mean kernel duration from HIP events on the
+                launch stream.
+  cpu_baseline  the reference's own classes (oracle/_ref, kind "reference") or the
+                CPU restatement (kind "port") timed on this box's host cores on a
+                bounded sample of the same workload.  Rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    p.add_argument("--width", type=int, default=0, help="override (dev only; marks the line reduced)")
+    p.add_argument("--height", type=int, default=0)
+    p.add_argument("--spp", type=int, default=0)
+    p.add_argument("--variant", type=int, default=0, help="kernel variant (dev A/B)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-f32", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
+    return p.parse_args()
+
+
+def cpu_baseline(rt, scene_name, cam, earth, target_seconds):
+    """Time the CPU path on this host: reference classes if the prebuilt driver is here, else the port."""
+    from oracle import orc
+
+    cores = os.cpu_count() or 1
+    W, H, depth = cam.image_width, cam.image_height, cam.max_depth
+    if os.path.exists(orc.REF_DRIVER):
+        def run(spp):
+            out = subprocess.check_output([orc.REF_DRIVER, "time", scene_name, str(rt.SCENE_SEED), earth, str(W), str(H), str(spp), str(depth),
+                                           str(rt.RENDER_SEED), str(cores)], timeout=600)
+            return json.loads(out.decode().strip().splitlines()[-1])
+        probe = run(1)
+        spp = max(1, min(16, int(target_seconds / max(probe["seconds"], 1e-3))))
+        res = run(spp) if spp > 1 else probe
+        return {"value": round(res["msamples_per_s"], 4), "unit": "Msamples/s", "cores": cores, "kind": "reference",
+                "sample": f"{scene_name} {W}x{H}x{res['spp']}spp depth {depth}, reference classes (oracle/_ref), {cores} threads, {res['seconds']:.1f} s"}
+    scene = rt.Scene.build(scene_name, image_file=earth)
+    def run(spp):
+        c = scene.camera(W, H, spp, depth)
+        t0 = time.time()
+        orc.render(scene.desc_ptr, c, rt.RENDER_SEED, cores)
+        return time.time() - t0
+    t1 = run(1)
+    spp = max(1, min(16, int(target_seconds / max(t1, 1e-3))))
+    t = run(spp) if spp > 1 else t1
+    return {"value": round(W * H * spp / t / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"{scene_name} {W}x{H}x{spp}spp depth {depth}, CPU restatement (oracle/rt_oracle.cpp), {cores} threads, {t:.1f} s"}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    import raytracingoneweekendapplication_amd as rt
+    from raytracingoneweekendapplication_amd import tiling
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n = args.gpus
+    if world != n:
+        if world == 1 and n > 1:
+            raise SystemExit(f"--gpus {n} needs a launcher: python -m torch.distributed.run --nproc-per-node {n} bench.py --gpus {n} ...")
+        n = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path exists for the product)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if n > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=n, device_id=dev)
+
+    # ---- inputs: scene + camera, resident in HBM before anything is timed
+    scene_name = rt.CONFIG_SCENES[args.config]
+    tmp = tempfile.mkdtemp(prefix="rtk_bench_")
+    earth = rt.write_synthetic_earth(os.path.join(tmp, "earth_synth.ppm"))
+    scene = rt.Scene.build(scene_name, rt.SCENE_SEED, earth)
+    cam = scene.camera(args.width, args.height, args.spp, 0)
+    W, H, spp, depth = cam.image_width, cam.image_height, cam.samples_per_pixel, cam.max_depth
+    reduced = bool(args.width or args.height or args.spp)
+    renderer = rt.Renderer(local_rank)
+    renderer.upload(scene)
+    info = renderer.scene_info()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def make_step(real_mode):
+        dtype = torch.float64 if real_mode == rt.RTK_REAL_F64 else torch.float32
+        tpr = tiling.tiles_per_rank(W, H, n)
+        image = torch.empty((H, W, 3), dtype=dtype, device=dev) if rank == 0 else None
+        rgb8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
+        compact = torch.empty((tpr, 3, 64), dtype=dtype, device=dev) if n > 1 else None
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+        def step(kernel_ms=None):
+            if kernel_ms is not None:
+                ev[0].record()
+            if n == 1:
+                renderer.render_device(cam, image.data_ptr(), rgb8.data_ptr(), real_mode=real_mode, variant=args.variant, stream=stream)
+            else:
+                renderer.render_device(cam, compact.data_ptr(), 0, real_mode=real_mode, rank=rank, n_ranks=n, variant=args.variant, stream=stream)
+            if kernel_ms is not None:
+                ev[1].record()
+            if n > 1:
+                gathered = tiling.gather_to_root(compact, n, rank)
+                if rank == 0:
+                    renderer.unpermute(W, H, n, real_mode, gathered.data_ptr(), image.data_ptr(), rgb8.data_ptr(), stream=stream)
+            if kernel_ms is not None:
+                ev[1].synchronize()
+                kernel_ms.append(ev[0].elapsed_time(ev[1]))
+        return step, image
+
+    def barrier():
+        if n > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(real_mode, steps, warmup):
+        step, image = make_step(real_mode)
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if n > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        # kernel duration: separate, event-bracketed launches on the same stream (not inside the timed region)
+        kernel_ms = []
+        for _ in range(min(steps, 5)):
+            step(kernel_ms)
+        barrier()
+        return elapsed, sum(kernel_ms) / len(kernel_ms), image
+
+    elapsed, kernel_ms, image = timed(rt.RTK_REAL_F64, args.steps, args.warmup)
+    samples_per_step = W * H * spp
+    value = samples_per_step * args.steps / elapsed / 1e6
+
+    # ---- roofline of the render kernel on rank 0: exact work counters -> algorithmic bytes per launch
+    roofline = None
+    counters = None
+    if rank == 0:
+        d_cnt = torch.zeros(12, dtype=torch.int64, device=dev)
+        tpr = tiling.tiles_per_rank(W, H, n)
+        scratch = torch.empty((tpr * 192,), dtype=torch.float64, device=dev) if n > 1 else torch.empty((H, W, 3), dtype=torch.float64, device=dev)
+        renderer.render_device(cam, scratch.data_ptr(), 0, real_mode=rt.RTK_REAL_F64, rank=rank, n_ranks=n, d_counters=d_cnt.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        counters = dict(zip(rt.COUNTER_FIELDS, [int(v) for v in d_cnt.tolist()]))
+        b_sample = rt.algorithmic_bytes_per_sample(counters, spp, rt.RTK_REAL_F64)
+        bytes_per_launch = b_sample * counters["samples"]
+        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                rec = json.load(open(tfile))
+                if rec.get("workload") == f"{scene_name} {W}x{H}x{spp}" and rec.get("n_gpus") == n and rec.get("dtype") == "f64":
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "kernel": renderer.kernel_name(rt.RTK_REAL_F64, args.variant), "kernel_ms": round(kernel_ms, 4),
+                    "algorithmic_bytes_per_sample": round(b_sample, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                    "compulsory_bytes": info["bytes_f64"] + W * H * 3 * 9,
+                    "per_sample": {k: round(counters[k] / counters["samples"], 4) for k in rt.COUNTER_FIELDS if k != "samples"}}
+
+    f32_mode = None
+    if not args.no_f32:
+        e32, k32, _ = timed(rt.RTK_REAL_F32, max(1, min(args.steps, 3)), 1)
+        if rank == 0:
+            f32_mode = {"value": round(samples_per_step * max(1, min(args.steps, 3)) / e32 / 1e6, 2), "unit": "Msamples/s", "kernel_ms": round(k32, 4),
+                        "note": "throughput mode; parity vs the double reference is statistical only (SURVEY.md 8(d)); not the headline"}
+
+    cpu = None
+    if rank == 0 and n == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(rt, scene_name, cam, earth, args.cpu_seconds)
+        except Exception as exc:  # the baseline is reported, never required
+            cpu = {"value": None, "unit": "Msamples/s", "cores": os.cpu_count(), "kind": "unavailable", "sample": f"failed: {exc}"}
+
+    if rank == 0:
+        line = {
+            "metric": "Msamples/sec (pixels x spp) on RTIOW final scene 1920x1080",
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{scene_name} {W}x{H}x{spp}spp depth {depth} (BASELINE configs[{int(args.config[1]) - 1}])",
+                       "tiles": "8x8 px per wave, interleaved over ranks", "parallelism": f"image tiles over {n} GPU(s) + 1 gather" if n > 1 else "1 GPU",
+                       "scene_seed": rt.SCENE_SEED, "render_seed": rt.RENDER_SEED, "program_ops": info["program_ops"], "reduced": reduced,
+                       "variant": args.variant},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "f32_mode": f32_mode,
+            "speedup_vs_cpu_baseline": (round(value / cpu["value"], 1) if cpu and cpu.get("value") else None),
+        }
+        print(json.dumps(line), flush=True)
+    if n > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

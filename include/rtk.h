@@ -272,7 +272,7 @@ int rtk_render_host(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts* 
                     double* h_linear, uint8_t* h_rgb8, rtk_work_counters* counters);
 
 /* Introspection of the uploaded scene's traversal program (for tests and
- * for the byte model): number of program records and device bytes per mode. */
+ * for the byte model): number of program slots (fused records) and device bytes per mode. */
 int rtk_scene_info(rtk_ctx* ctx, int32_t* n_program_ops, int64_t* bytes_f64, int64_t* bytes_f32);
 
 /* Names of the kernel symbols rtk_render_device launches for (real_mode,

@@ -262,10 +262,67 @@ void store3(real* dst, const rtk_vec3& v) {
 template <typename real>
 int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScene<real>& out) {
     out.release();
-    std::vector<BoxRec<real>> boxes(sc.n_bvh_boxes);
-    for (int32_t i = 0; i < sc.n_bvh_boxes; i++) {
-        const rtk_aabb& b = sc.bvh_boxes[i];
-        boxes[i] = BoxRec<real>{real(b.xmin), real(b.xmax), real(b.ymin), real(b.ymax), real(b.zmin), real(b.zmax), {real(0), real(0)}};
+    // ---- the fused traversal program: one or more slots per op, skip links
+    // translated from op indices to slot indices
+    std::vector<uint32_t> slot_of_op(prog.ops.size() + 1, 0);
+    auto slot_kind = [&](const Op& op) -> uint32_t {
+        uint32_t kind = op.kind_payload & 15u;
+        if (kind == OP_SPHERE) {
+            const rtk_sphere& s = sc.spheres[op.kind_payload >> 4];
+            if (s.center_dir.x != 0 || s.center_dir.y != 0 || s.center_dir.z != 0) kind = OP_SPHERE_MOVING;
+        }
+        return kind;
+    };
+    for (size_t i = 0; i < prog.ops.size(); i++) slot_of_op[i + 1] = slot_of_op[i] + uint32_t(slots_of<real>(slot_kind(prog.ops[i])));
+    std::vector<Slot<real>> slots(slot_of_op.back());
+    std::memset(slots.data(), 0, slots.size() * sizeof(Slot<real>));
+    auto pack = [&](Slot<real>* rec, const double* vals, int n) {
+        for (int e = 0; e < n; e++) rec[e / Slot<real>::kReals].v[e % Slot<real>::kReals] = real(vals[e]);
+    };
+    for (size_t i = 0; i < prog.ops.size(); i++) {
+        const Op& op = prog.ops[i];
+        const uint32_t kind = slot_kind(op), payload = op.kind_payload >> 4;
+        Slot<real>* rec = &slots[slot_of_op[i]];
+        rec->kind_payload = make_op(kind, payload);
+        rec->aux = op.aux;
+        switch (kind) {
+            case OP_BOX: {
+                const rtk_aabb& b = sc.bvh_boxes[payload];
+                const double vals[6] = {b.xmin, b.xmax, b.ymin, b.ymax, b.zmin, b.zmax};
+                pack(rec, vals, 6);
+                rec->aux = slot_of_op[op.aux];
+                break;
+            }
+            case OP_SPHERE:
+            case OP_SPHERE_MOVING: {
+                const rtk_sphere& s = sc.spheres[payload];
+                const double vals[4] = {s.center0.x, s.center0.y, s.center0.z, s.radius};
+                pack(rec, vals, 4);
+                if (kind == OP_SPHERE_MOVING) {
+                    const double dir[3] = {s.center_dir.x, s.center_dir.y, s.center_dir.z};
+                    pack(rec + 1, dir, 3);
+                }
+                break;
+            }
+            case OP_QUAD: {
+                const rtk_quad& q = sc.quads[payload];
+                const double vals[16] = {q.normal.x, q.normal.y, q.normal.z, q.D, q.Q.x, q.Q.y, q.Q.z, q.w.x, q.w.y, q.w.z,
+                                         q.v.x, q.v.y, q.v.z, q.u.x, q.u.y, q.u.z};
+                pack(rec, vals, 16);
+                break;
+            }
+            case OP_TRI: {
+                const rtk_triangle& t = sc.triangles[payload];
+                // v0v1 = p1 - p0, v0v2 = p2 - p0 (triangle.h:67-68) in double, then to `real`
+                const double vals[9] = {t.p2.x - t.p0.x, t.p2.y - t.p0.y, t.p2.z - t.p0.z, t.p1.x - t.p0.x, t.p1.y - t.p0.y, t.p1.z - t.p0.z,
+                                        t.p0.x, t.p0.y, t.p0.z};
+                pack(rec, vals, 9);
+                break;
+            }
+            case OP_MED_MID: rec->aux = slot_of_op[op.aux]; break;
+            case OP_MED_END: rec->v[0] = real(sc.media[payload].neg_inv_density); break;
+            default: break;
+        }
     }
     std::vector<SphereRec<real>> spheres(sc.n_spheres);
     for (int32_t i = 0; i < sc.n_spheres; i++) {
@@ -365,8 +422,7 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
         lights[i].size = real(sc.lights[i].size);
     }
     int rc;
-    if ((rc = out.upload(prog.ops, &out.view.ops)) != RTK_OK) return rc;
-    if ((rc = out.upload(boxes, &out.view.boxes)) != RTK_OK) return rc;
+    if ((rc = out.upload(slots, &out.view.program)) != RTK_OK) return rc;
     if ((rc = out.upload(spheres, &out.view.spheres)) != RTK_OK) return rc;
     if ((rc = out.upload(quads, &out.view.quads)) != RTK_OK) return rc;
     if ((rc = out.upload(tris, &out.view.tris)) != RTK_OK) return rc;
@@ -378,7 +434,7 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
     if ((rc = out.upload(perlins, &out.view.perlins)) != RTK_OK) return rc;
     if ((rc = out.upload(chains, &out.view.chains)) != RTK_OK) return rc;
     if ((rc = out.upload(lights, &out.view.lights)) != RTK_OK) return rc;
-    out.view.n_ops = int32_t(prog.ops.size());
+    out.view.n_slots = int32_t(slots.size());
     out.view.n_lights = sc.n_lights;
     return RTK_OK;
 }
@@ -411,7 +467,12 @@ struct rtk_ctx {
     int32_t n_ops = 0;
     DeviceScene<double> scene64;
     DeviceScene<float> scene32;
+    // Words the persistent waves pull tile indices from; one per launch in a
+    // small ring so that back-to-back launches on a stream never share one.
+    unsigned int* tile_counters = nullptr;
+    unsigned int next_counter = 0;
 };
+constexpr unsigned int kCounterRing = 256;
 
 extern "C" {
 
@@ -434,6 +495,11 @@ int rtk_init(int device, rtk_ctx** out_ctx) {
     RTK_HIP(hipSetDevice(device));
     auto* ctx = new rtk_ctx;
     ctx->device = device;
+    hipError_t me = hipMalloc(reinterpret_cast<void**>(&ctx->tile_counters), kCounterRing * sizeof(unsigned int));
+    if (me != hipSuccess) {
+        delete ctx;
+        return fail(RTK_ERR_HIP, "hipMalloc(tile counters) failed: %s", hipGetErrorString(me));
+    }
     *out_ctx = ctx;
     return RTK_OK;
 }
@@ -443,6 +509,7 @@ int rtk_destroy(rtk_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     ctx->scene64.release();
     ctx->scene32.release();
+    if (ctx->tile_counters) (void)hipFree(ctx->tile_counters);
     delete ctx;
     return RTK_OK;
 }
@@ -501,13 +568,15 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
     tm.compact = opts->n_ranks > 1 ? 1 : 0;
     hipStream_t stream = static_cast<hipStream_t>(opts->stream);
     auto* counters = reinterpret_cast<unsigned long long*>(d_counters);
+    unsigned int* tile_counter = ctx->tile_counters + (ctx->next_counter++ % kCounterRing);
+    const bool allow_lds = opts->variant != 1;  // variant 1: keep the program in global memory (A/B)
     hipError_t e;
     if (opts->real_mode == RTK_REAL_F64)
-        e = launch_render<double>(ctx->scene64.view, to_device_camera<double>(*cam), tm, opts->seed, ctx->features, opts->count_work != 0, d_linear, d_rgb8,
-                                  counters, stream);
+        e = launch_render<double>(ctx->scene64.view, to_device_camera<double>(*cam), tm, opts->seed, ctx->features, opts->count_work != 0, allow_lds,
+                                  d_linear, d_rgb8, counters, tile_counter, stream);
     else
-        e = launch_render<float>(ctx->scene32.view, to_device_camera<float>(*cam), tm, opts->seed, ctx->features, opts->count_work != 0, d_linear, d_rgb8,
-                                 counters, stream);
+        e = launch_render<float>(ctx->scene32.view, to_device_camera<float>(*cam), tm, opts->seed, ctx->features, opts->count_work != 0, allow_lds,
+                                 d_linear, d_rgb8, counters, tile_counter, stream);
     if (e != hipSuccess) return fail(RTK_ERR_HIP, "render kernel launch failed: %s", hipGetErrorString(e));
     return RTK_OK;
 }
@@ -578,16 +647,17 @@ int rtk_render_host(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts* 
 
 int rtk_scene_info(rtk_ctx* ctx, int32_t* n_program_ops, int64_t* bytes_f64, int64_t* bytes_f32) {
     if (!ctx || !ctx->has_scene) return fail(RTK_ERR_NO_SCENE, "rtk_scene_info: no scene uploaded");
-    if (n_program_ops) *n_program_ops = ctx->n_ops;
+    if (n_program_ops) *n_program_ops = ctx->scene64.view.n_slots;
     if (bytes_f64) *bytes_f64 = ctx->scene64.bytes;
     if (bytes_f32) *bytes_f32 = ctx->scene32.bytes;
     return RTK_OK;
 }
 
 const char* rtk_kernel_name(rtk_ctx* ctx, int real_mode, int variant) {
-    (void)variant;
     if (!ctx || !ctx->has_scene) return "";
-    return render_kernel_name(real_mode == RTK_REAL_F64, ctx->features, false);
+    const bool f64 = real_mode == RTK_REAL_F64;
+    const bool lds = variant != 1 && (f64 ? program_fits_lds(ctx->scene64.view) : program_fits_lds(ctx->scene32.view));
+    return render_kernel_name(f64, ctx->features, false, lds);
 }
 
 }  // extern "C"

@@ -4,7 +4,8 @@
 // parity mode, float for the throughput mode).
 //
 // The scene graph of rtk_scene_desc is compiled into a linear TRAVERSAL PROGRAM:
-// one 8-byte op per visit, laid out in exactly the order the reference's
+// one fused record ("slot": 8-byte header + the reals the visit needs, 64 B in f64,
+// 32 B in f32) per visit, laid out in exactly the order the reference's
 // recursion visits things (bvh.h:64-72: box test, then left subtree, then right
 // subtree, both always), with a skip link on every box op.  Executing the
 // program from op 0 to OP_END with "on a failed box test jump to op.aux" performs
@@ -32,14 +33,15 @@ namespace rtk {
 
 enum OpKind : uint32_t {
     OP_END = 0,
-    OP_BOX = 1,        // payload = box index, aux = pc to continue at when the slab test fails
-    OP_SPHERE = 2,     // payload = sphere index, aux = chain id
-    OP_QUAD = 3,       // payload = quad index, aux = chain id
-    OP_TRI = 4,        // payload = triangle index, aux = chain id
-    OP_CHAIN = 5,      // payload = chain id to make current, aux = number of transform entries it stands for
-    OP_MED_BEGIN = 6,  // payload = medium index
-    OP_MED_MID = 7,    // payload = medium index, aux = pc after the matching OP_MED_END
-    OP_MED_END = 8     // payload = medium index, aux = chain id
+    OP_BOX = 1,        // 1 slot : v = xmin,xmax,ymin,ymax,zmin,zmax; aux = pc to continue at when the slab test fails
+    OP_SPHERE = 2,     // 1 slot : v = cx,cy,cz,radius (static sphere); payload = sphere index, aux = chain id
+    OP_QUAD = 3,       // 3 slots: n(3),D,Q(3),w(3),v(3),u(3) packed over the slots' v[]; payload = quad index, aux = chain id
+    OP_TRI = 4,        // 2 slots: e2(3),e1(3),p0(3); payload = triangle index, aux = chain id
+    OP_CHAIN = 5,      // 1 slot : payload = chain id to make current, aux = number of transform entries it stands for
+    OP_MED_BEGIN = 6,  // 1 slot : payload = medium index
+    OP_MED_MID = 7,    // 1 slot : payload = medium index, aux = pc after the matching OP_MED_END
+    OP_MED_END = 8,    // 1 slot : v[0] = neg_inv_density; payload = medium index, aux = chain id
+    OP_SPHERE_MOVING = 9  // 2 slots: as OP_SPHERE, then v = dx,dy,dz (center2 - center1)
 };
 
 struct Op {
@@ -47,6 +49,20 @@ struct Op {
     uint32_t aux;
 };
 inline constexpr uint32_t make_op(uint32_t kind, uint32_t payload) { return kind | (payload << 4); }
+
+// The fused program record.  pc counts slots; a box visit reads exactly one.
+template <typename real>
+struct alignas(16) Slot {
+    static constexpr int kReals = sizeof(real) == 8 ? 7 : 6;
+    real v[kReals];              // first: a box's six bounds are then whole 16-byte LDS reads (ds_read_b128)
+    uint32_t kind_payload, aux;  // header last: f64 at byte 56, f32 at byte 24
+};
+static_assert(sizeof(Slot<double>) == 64 && sizeof(Slot<float>) == 32, "slot size");
+
+template <typename real>
+inline constexpr int slots_of(uint32_t kind) {
+    return kind == OP_QUAD ? 3 : ((kind == OP_TRI || kind == OP_SPHERE_MOVING) ? 2 : 1);
+}
 
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 constexpr int kMaxChain = 4;
@@ -64,12 +80,6 @@ enum Feature : uint32_t {
 };
 constexpr uint32_t kFeatLean = 0;                       // spheres + lambertian/metal/dielectric with solid colours
 constexpr uint32_t kFeatAll = 0x7F;
-
-template <typename real>
-struct alignas(16) BoxRec {  // aabb of a bvh_node (aabb.h:12)
-    real xmin, xmax, ymin, ymax, zmin, zmax;
-    real _pad[2];            // f64: 64 B, f32: 32 B -> whole records per 16-B load
-};
 
 template <typename real>
 struct alignas(16) SphereRec {  // sphere.h:60-64
@@ -143,8 +153,7 @@ struct CameraRec {  // Camera.txt:122-131
 
 template <typename real>
 struct SceneView {  // device pointers, passed to the kernel by value
-    const Op* ops;
-    const BoxRec<real>* boxes;
+    const Slot<real>* program;  // the traversal program (copied to LDS by each workgroup when it fits)
     const SphereRec<real>* spheres;
     const QuadRec<real>* quads;
     const TriRec<real>* tris;
@@ -156,11 +165,11 @@ struct SceneView {  // device pointers, passed to the kernel by value
     const PerlinRec<real>* perlins;
     const ChainRec<real>* chains;
     const LightRec<real>* lights;
-    int32_t n_ops, n_lights;
+    int32_t n_slots, n_lights;
 };
 
 struct TileMap {  // which tiles this launch renders and where the pixels go
-    int32_t tiles_x, tiles_y, n_tiles_local;
+    int32_t tiles_x, tiles_y, n_tiles_local;  // tiles are pulled by persistent waves from an atomic counter
     int32_t rank, n_ranks;
     int32_t compact;  // 1: write [local_tile][3][64] reals, 0: write the row-major image
 };

@@ -10,16 +10,23 @@ namespace rtk {
 
 // Enqueue the render kernel for one rank's tiles.  `features` selects the
 // kernel instantiation (kFeatLean or kFeatAll); `count` selects the
-// work-counting instantiation (always the full-feature kernel).
+// work-counting instantiation (always the full-feature kernel).  tile_counter is
+// a device word the persistent waves pull tile indices from (zeroed on `stream`
+// before the launch).
 template <typename real>
 hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>& cam, const TileMap& tmap, uint32_t seed, uint32_t features, bool count,
-                         void* out_linear, uint8_t* out_rgb8, unsigned long long* counters, hipStream_t stream);
+                         bool allow_lds, void* out_linear, uint8_t* out_rgb8, unsigned long long* counters, unsigned int* tile_counter,
+                         hipStream_t stream);
+
+// Whether the traversal program of `sc` can be staged in one CU's LDS.
+template <typename real>
+bool program_fits_lds(const SceneView<real>& sc);
 
 template <typename real>
 hipError_t launch_unpermute(const void* gathered, int width, int height, int n_ranks, long long tiles_per_rank, void* out_linear, uint8_t* out_rgb8,
                             hipStream_t stream);
 
-const char* render_kernel_name(bool f64, uint32_t features, bool count);
+const char* render_kernel_name(bool f64, uint32_t features, bool count, bool lds);
 
 }  // namespace rtk
 

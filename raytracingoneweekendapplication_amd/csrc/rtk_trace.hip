@@ -171,23 +171,23 @@ RTK_DEV void unapply_chain(const ChainRec<real>* __restrict__ chains, uint32_t c
 // 0*inf are handled exactly as its `<`/`>` comparisons handle them (the select
 // keeps the reference's else-branch, fmax/fmin drop a NaN operand).
 template <typename real>
-RTK_DEV bool slab_test(const BoxRec<real>& b, V3<real> o, V3<real> inv, real tmin, real tmax) {
+RTK_DEV bool slab_test(const Slot<real>& b, V3<real> o, V3<real> inv, real tmin, real tmax) {
     {
-        real t0 = (b.xmin - o.x) * inv.x, t1 = (b.xmax - o.x) * inv.x;
+        real t0 = (b.v[0] - o.x) * inv.x, t1 = (b.v[1] - o.x) * inv.x;
         bool lt = t0 < t1;
         real nr = lt ? t0 : t1, fr = lt ? t1 : t0;
         tmin = rt_fmax(nr, tmin);
         tmax = rt_fmin(fr, tmax);
     }
     {
-        real t0 = (b.ymin - o.y) * inv.y, t1 = (b.ymax - o.y) * inv.y;
+        real t0 = (b.v[2] - o.y) * inv.y, t1 = (b.v[3] - o.y) * inv.y;
         bool lt = t0 < t1;
         real nr = lt ? t0 : t1, fr = lt ? t1 : t0;
         tmin = rt_fmax(nr, tmin);
         tmax = rt_fmin(fr, tmax);
     }
     {
-        real t0 = (b.zmin - o.z) * inv.z, t1 = (b.zmax - o.z) * inv.z;
+        real t0 = (b.v[4] - o.z) * inv.z, t1 = (b.v[5] - o.z) * inv.z;
         bool lt = t0 < t1;
         real nr = lt ? t0 : t1, fr = lt ? t1 : t0;
         tmin = rt_fmax(nr, tmin);
@@ -196,13 +196,22 @@ RTK_DEV bool slab_test(const BoxRec<real>& b, V3<real> o, V3<real> inv, real tmi
     return tmax > tmin;
 }
 
-// sphere::hit up to the accepted root (sphere.h:32-49).
+// Element e of a primitive whose reals are packed over consecutive slots.
+template <typename real, int E>
+RTK_DEV real packed(const Slot<real>* rec) {
+    return rec[E / Slot<real>::kReals].v[E % Slot<real>::kReals];
+}
+template <typename real, int E>
+RTK_DEV V3<real> packed3(const Slot<real>* rec) {
+    return V3<real>{packed<real, E>(rec), packed<real, E + 1>(rec), packed<real, E + 2>(rec)};
+}
+
+// sphere::hit up to the accepted root (sphere.h:32-49); cc = center.at(r.time()).
 template <typename real>
-RTK_DEV bool sphere_root(const SphereRec<real>& s, V3<real> o, V3<real> d, real a, real tm, real tmin, real tmax, real& root) {
-    V3<real> cc = mk(s.cx, s.cy, s.cz) + scale(tm, mk(s.dx, s.dy, s.dz));
+RTK_DEV bool sphere_root(V3<real> cc, real radius, V3<real> o, V3<real> d, real a, real tmin, real tmax, real& root) {
     V3<real> oc = cc - o;
     real h = dot(d, oc);
-    real c = length_squared(oc) - s.radius * s.radius;
+    real c = length_squared(oc) - radius * radius;
     real disc = h * h - a * c;
     if (disc < real(0)) return false;
     real sq = rt_sqrt(disc);
@@ -215,33 +224,35 @@ RTK_DEV bool sphere_root(const SphereRec<real>& s, V3<real> o, V3<real> d, real 
     return true;
 }
 
-// quad::hit (quad.h:29-73); alpha/beta returned for the deferred uv.
+// quad::hit (quad.h:29-73) on the packed record n(3),D,Q(3),w(3),v(3),u(3).
 template <typename real>
-RTK_DEV bool quad_test(const QuadRec<real>& q, V3<real> o, V3<real> d, real tmin, real tmax, real& t_out, real& alpha, real& beta) {
-    V3<real> n = ld3(q.n);
+RTK_DEV bool quad_test(const Slot<real>* rec, V3<real> o, V3<real> d, real tmin, real tmax, real& t_out, real& alpha, real& beta) {
+    V3<real> n = packed3<real, 0>(rec);
     real denom = dot(n, d);
     if (rt_fabs(denom) < real(1e-8)) return false;
-    real t = (q.D - dot(n, o)) / denom;
+    real t = (packed<real, 3>(rec) - dot(n, o)) / denom;
     if (!(tmin <= t && t <= tmax)) return false;
     V3<real> P = o + scale(t, d);
-    V3<real> planar = P - ld3(q.Q);
-    alpha = dot(ld3(q.w), cross(planar, ld3(q.v)));
-    beta = dot(ld3(q.w), cross(ld3(q.u), planar));
+    V3<real> planar = P - packed3<real, 4>(rec);
+    V3<real> w = packed3<real, 7>(rec);
+    alpha = dot(w, cross(planar, packed3<real, 10>(rec)));
+    beta = dot(w, cross(packed3<real, 13>(rec), planar));
     if (!(real(0) <= alpha && alpha <= real(1)) || !(real(0) <= beta && beta <= real(1))) return false;
     t_out = t;
     return true;
 }
 
 // triangle::hit (triangle.h:65-122): Moeller-Trumbore with the reference's float
-// determinant (triangle.h:72,77) and float barycentrics (triangle.h:96-98).
+// determinant (triangle.h:72,77) and float barycentrics (triangle.h:96-98), on
+// the packed record e2(3),e1(3),p0(3).
 template <typename real>
-RTK_DEV bool tri_test(const TriRec<real>& tr, V3<real> o, V3<real> d, real tmin, real tmax, real& t_out, float& fa, float& fb, float& fg) {
-    V3<real> e1 = ld3(tr.e1), e2 = ld3(tr.e2);
+RTK_DEV bool tri_test(const Slot<real>* rec, V3<real> o, V3<real> d, real tmin, real tmax, real& t_out, float& fa, float& fb, float& fg) {
+    V3<real> e2 = packed3<real, 0>(rec), e1 = packed3<real, 3>(rec);
     V3<real> pvec = cross(d, e2);
     float det = float(dot(e1, pvec));
     if (__builtin_fabsf(det) < real(1e-8)) return false;
     float inv_det = 1.0f / det;
-    V3<real> tvec = o - ld3(tr.p0);
+    V3<real> tvec = o - packed3<real, 6>(rec);
     real u = dot(tvec, pvec) * real(inv_det);
     if (u < real(0) || u > real(1)) return false;
     V3<real> qvec = cross(tvec, e1);
@@ -258,106 +269,143 @@ RTK_DEV bool tri_test(const TriRec<real>& tr, V3<real> o, V3<real> d, real tmin,
     return true;
 }
 
-// world.hit(r, interval(0.001, inf), rec) (Camera.txt:211): run the traversal
-// program.  Returns the closest t and the op that produced it (kNoHit: miss).
-template <typename real, uint32_t FEAT, bool COUNT>
-RTK_DEV void closest_hit(const SceneView<real>& sc, V3<real> wo, V3<real> wd, real tm, uint32_t& rng, Counters<COUNT>& cnt, real& best_t_out,
-                         uint32_t& best_pc_out) {
-    V3<real> o = wo, d = wd;
-    V3<real> inv = mk(real(1) / d.x, real(1) / d.y, real(1) / d.z);  // aabb.h:67, hoisted: same value per box
-    real a = length_squared(d);                                      // sphere.h:35, hoisted likewise
-    real tmin = real(0.001), best_t = real_inf<real>();
-    uint32_t best_pc = kNoHit;
-    // constant_medium::hit nests two closest-hit queries of its boundary
-    // (constant_medium.h:23,26); the outer query state is parked here meanwhile.
-    real sv_tmin = 0, sv_best_t = 0, rec1_t = 0;
-    uint32_t sv_best_pc = kNoHit;
+// ------------------------------------------------------------------ lane state --
+// Everything a lane carries between scheduler iterations.  One lane = one pixel;
+// it walks that pixel's samples in order, each sample's segments in order, and
+// each segment's traversal program in order -- the same sequence of arithmetic as
+// the reference's recursion for that pixel, merely interleaved with other lanes.
+template <typename real>
+struct Lane {
+    V3<real> ro, rd;         // world-space ray of the current segment (ray_color's `r`)
+    V3<real> o, d, inv;      // the ray in the current chain's object space, and 1/d (aabb.h:67, hoisted: same value per box)
+    real a, tm;              // d.d (sphere.h:35, hoisted likewise); ray time
+    real tmin, best_t;       // current query interval: (tmin, closest so far)
+    real sv_tmin, sv_best_t, rec1_t;  // constant_medium::hit nests two closest-hit queries of its boundary
+                                      // (constant_medium.h:23,26); the outer query is parked here meanwhile
+    V3<real> throughput, radiance, sum;
+    uint32_t pc, best_pc, sv_best_pc, rng;
+    int depth, s;
+};
 
-    uint32_t pc = 0;
-    for (;;) {
-        const Op op = sc.ops[pc];
-        const uint32_t kind = op.kind_payload & 15u;
-        const uint32_t idx = op.kind_payload >> 4;
-        if (kind == OP_BOX) {
-            cnt.inc(C_BOX);
-            const bool hit = slab_test(sc.boxes[idx], o, inv, tmin, best_t);
-            pc = hit ? pc + 1 : op.aux;
-            continue;
+// world.hit(r, interval(0.001, inf), rec) (Camera.txt:211) starts here.
+template <typename real, bool COUNT>
+RTK_DEV void begin_segment(Lane<real>& L, Counters<COUNT>& cnt) {
+    cnt.inc(C_SEGMENTS);
+    L.o = L.ro;
+    L.d = L.rd;
+    L.inv = mk(real(1) / L.d.x, real(1) / L.d.y, real(1) / L.d.z);
+    L.a = length_squared(L.d);
+    L.tmin = real(0.001);
+    L.best_t = real_inf<real>();
+    L.best_pc = kNoHit;
+    L.pc = 0;
+}
+
+// bvh_node::hit's box test (bvh.h:65): on a miss skip the whole subtree.
+template <typename real, bool COUNT>
+RTK_DEV void step_box(Lane<real>& L, const Slot<real>& rec, Counters<COUNT>& cnt) {
+    cnt.inc(C_BOX);
+    const bool hit = slab_test(rec, L.o, L.inv, L.tmin, L.best_t);
+    L.pc = hit ? L.pc + 1 : rec.aux;
+}
+
+// sphere::hit of a stationary sphere.
+template <typename real, bool COUNT>
+RTK_DEV void step_sphere(Lane<real>& L, const Slot<real>& rec, Counters<COUNT>& cnt) {
+    cnt.inc(C_SPHERE);
+    real r;
+    if (sphere_root(mk(rec.v[0], rec.v[1], rec.v[2]), rec.v[3], L.o, L.d, L.a, L.tmin, L.best_t, r)) {
+        L.best_t = r;
+        L.best_pc = L.pc;
+    }
+    L.pc += 1;
+}
+
+// Every other record kind (moving sphere, quad, triangle, chain switch, the three
+// medium ops).  `rec` points at the record in the program (LDS or global).
+template <typename real, uint32_t FEAT, bool COUNT>
+RTK_DEV void step_other(Lane<real>& L, const Slot<real>* __restrict__ rec, const SceneView<real>& sc, Counters<COUNT>& cnt) {
+    const uint32_t kp = rec->kind_payload;
+    const uint32_t kind = kp & 15u;
+    if (kind == OP_SPHERE_MOVING) {
+        cnt.inc(C_SPHERE);
+        real r;
+        V3<real> cc = mk(rec->v[0], rec->v[1], rec->v[2]) + scale(L.tm, mk(rec[1].v[0], rec[1].v[1], rec[1].v[2]));
+        if (sphere_root(cc, rec->v[3], L.o, L.d, L.a, L.tmin, L.best_t, r)) {
+            L.best_t = r;
+            L.best_pc = L.pc;
         }
-        if (kind == OP_END) break;
-        if (kind == OP_SPHERE) {
-            cnt.inc(C_SPHERE);
-            real r;
-            if (sphere_root(sc.spheres[idx], o, d, a, tm, tmin, best_t, r)) {
-                best_t = r;
-                best_pc = pc;
-            }
-        } else if ((FEAT & F_QUAD) && kind == OP_QUAD) {
-            cnt.inc(C_QUAD);
-            real t, al, be;
-            if (quad_test(sc.quads[idx], o, d, tmin, best_t, t, al, be)) {
-                best_t = t;
-                best_pc = pc;
-            }
-        } else if ((FEAT & F_TRI) && kind == OP_TRI) {
-            cnt.inc(C_TRI);
-            real t;
-            float fa, fb, fg;
-            if (tri_test(sc.tris[idx], o, d, tmin, best_t, t, fa, fb, fg)) {
-                best_t = t;
-                best_pc = pc;
-            }
-        } else if ((FEAT & F_XFORM) && kind == OP_CHAIN) {
-            cnt.inc(C_XFORM, op.aux);
-            apply_chain(sc.chains, idx, wo, wd, o, d);
-            inv = mk(real(1) / d.x, real(1) / d.y, real(1) / d.z);
-            a = length_squared(d);
-        } else if ((FEAT & F_MEDIA) && kind == OP_MED_BEGIN) {
-            cnt.inc(C_MEDIUM);
-            sv_tmin = tmin;
-            sv_best_t = best_t;
-            sv_best_pc = best_pc;
-            tmin = -real_inf<real>();
-            best_t = real_inf<real>();
-            best_pc = kNoHit;
-        } else if ((FEAT & F_MEDIA) && kind == OP_MED_MID) {
-            if (best_pc == kNoHit) {  // constant_medium.h:23-24
-                tmin = sv_tmin;
-                best_t = sv_best_t;
-                best_pc = sv_best_pc;
-                pc = op.aux;
-                continue;
-            }
-            rec1_t = best_t;
-            tmin = rec1_t + real(0.0001);  // constant_medium.h:26
-            best_t = real_inf<real>();
-            best_pc = kNoHit;
-        } else if ((FEAT & F_MEDIA) && kind == OP_MED_END) {
-            const bool hit2 = best_pc != kNoHit;
-            real r2 = best_t;
-            tmin = sv_tmin;
-            best_t = sv_best_t;
-            best_pc = sv_best_pc;
-            if (hit2) {  // constant_medium.h:29-50
-                real r1 = rec1_t;
-                if (r1 < tmin) r1 = tmin;
-                if (r2 > best_t) r2 = best_t;
-                if (r1 < r2) {
-                    if (r1 < real(0)) r1 = real(0);
-                    const real ray_length = rt_sqrt(a);
-                    const real inside = (r2 - r1) * ray_length;
-                    const real hit_distance = sc.media[idx].neg_inv_density * rt_log(rnd<real>(rng, cnt));
-                    if (!(hit_distance > inside)) {
-                        best_t = r1 + hit_distance / ray_length;
-                        best_pc = pc;
-                    }
+        L.pc += 2;
+    } else if ((FEAT & F_QUAD) && kind == OP_QUAD) {
+        cnt.inc(C_QUAD);
+        real t, al, be;
+        if (quad_test(rec, L.o, L.d, L.tmin, L.best_t, t, al, be)) {
+            L.best_t = t;
+            L.best_pc = L.pc;
+        }
+        L.pc += 3;
+    } else if ((FEAT & F_TRI) && kind == OP_TRI) {
+        cnt.inc(C_TRI);
+        real t;
+        float fa, fb, fg;
+        if (tri_test(rec, L.o, L.d, L.tmin, L.best_t, t, fa, fb, fg)) {
+            L.best_t = t;
+            L.best_pc = L.pc;
+        }
+        L.pc += 2;
+    } else if ((FEAT & F_XFORM) && kind == OP_CHAIN) {
+        cnt.inc(C_XFORM, rec->aux);
+        apply_chain(sc.chains, kp >> 4, L.ro, L.rd, L.o, L.d);
+        L.inv = mk(real(1) / L.d.x, real(1) / L.d.y, real(1) / L.d.z);
+        L.a = length_squared(L.d);
+        L.pc += 1;
+    } else if ((FEAT & F_MEDIA) && kind == OP_MED_BEGIN) {
+        cnt.inc(C_MEDIUM);
+        L.sv_tmin = L.tmin;
+        L.sv_best_t = L.best_t;
+        L.sv_best_pc = L.best_pc;
+        L.tmin = -real_inf<real>();
+        L.best_t = real_inf<real>();
+        L.best_pc = kNoHit;
+        L.pc += 1;
+    } else if ((FEAT & F_MEDIA) && kind == OP_MED_MID) {
+        if (L.best_pc == kNoHit) {  // constant_medium.h:23-24
+            L.tmin = L.sv_tmin;
+            L.best_t = L.sv_best_t;
+            L.best_pc = L.sv_best_pc;
+            L.pc = rec->aux;
+        } else {
+            L.rec1_t = L.best_t;
+            L.tmin = L.rec1_t + real(0.0001);  // constant_medium.h:26
+            L.best_t = real_inf<real>();
+            L.best_pc = kNoHit;
+            L.pc += 1;
+        }
+    } else if ((FEAT & F_MEDIA) && kind == OP_MED_END) {
+        const bool hit2 = L.best_pc != kNoHit;
+        real r2 = L.best_t;
+        L.tmin = L.sv_tmin;
+        L.best_t = L.sv_best_t;
+        L.best_pc = L.sv_best_pc;
+        if (hit2) {  // constant_medium.h:29-50
+            real r1 = L.rec1_t;
+            if (r1 < L.tmin) r1 = L.tmin;
+            if (r2 > L.best_t) r2 = L.best_t;
+            if (r1 < r2) {
+                if (r1 < real(0)) r1 = real(0);
+                const real ray_length = rt_sqrt(L.a);
+                const real inside = (r2 - r1) * ray_length;
+                const real hit_distance = rec->v[0] * rt_log(rnd<real>(L.rng, cnt));
+                if (!(hit_distance > inside)) {
+                    L.best_t = r1 + hit_distance / ray_length;
+                    L.best_pc = L.pc;
                 }
             }
         }
-        pc++;
+        L.pc += 1;
+    } else {
+        L.pc += 1;  // unreachable for a validated program
     }
-    best_t_out = best_t;
-    best_pc_out = best_pc;
 }
 
 // ------------------------------------------------------------------ textures --
@@ -453,11 +501,12 @@ struct Surface {  // hit_record (hittable.h:11-27)
 
 // Build the hit record of the winning op (the deferred half of *.hit).
 template <typename real, uint32_t FEAT>
-RTK_DEV void make_surface(const SceneView<real>& sc, uint32_t best_pc, real t, V3<real> wo, V3<real> wd, real tm, Surface<real>& sf) {
-    const Op op = sc.ops[best_pc];
-    const uint32_t kind = op.kind_payload & 15u;
-    const uint32_t idx = op.kind_payload >> 4;
-    const uint32_t chain = (FEAT & F_XFORM) ? op.aux : 0u;
+RTK_DEV void make_surface(const Slot<real>* __restrict__ prog, const SceneView<real>& sc, uint32_t best_pc, real t, V3<real> wo, V3<real> wd, real tm,
+                          Surface<real>& sf) {
+    const Slot<real>* rec = prog + best_pc;
+    const uint32_t kind = rec->kind_payload & 15u;
+    const uint32_t idx = rec->kind_payload >> 4;
+    const uint32_t chain = (FEAT & F_XFORM) ? rec->aux : 0u;
     V3<real> o = wo, d = wd;
     if (FEAT & F_XFORM) apply_chain(sc.chains, chain, wo, wd, o, d);
     sf.p = o + scale(t, d);
@@ -465,7 +514,7 @@ RTK_DEV void make_surface(const SceneView<real>& sc, uint32_t best_pc, real t, V
     sf.v = real(0);
     V3<real> outward;
     bool face_from_ray = true;
-    if (kind == OP_SPHERE) {  // sphere.h:50-56,67-73
+    if (kind == OP_SPHERE || kind == OP_SPHERE_MOVING) {  // sphere.h:50-56,67-73
         const SphereRec<real>& s = sc.spheres[idx];
         V3<real> cc = mk(s.cx, s.cy, s.cz) + scale(tm, mk(s.dx, s.dy, s.dz));
         outward = divide(sf.p - cc, s.radius);
@@ -488,7 +537,7 @@ RTK_DEV void make_surface(const SceneView<real>& sc, uint32_t best_pc, real t, V
         const TriRec<real>& tr = sc.tris[idx];
         real tt;
         float fa = 0, fb = 0, fg = 0;
-        tri_test(tr, o, d, -real_inf<real>(), real_inf<real>(), tt, fa, fb, fg);
+        tri_test(rec, o, d, -real_inf<real>(), real_inf<real>(), tt, fa, fb, fg);
         sf.u = real(fa * tr.uv0[0] + fb * tr.uv1[0] + fg * tr.uv2[0]);
         sf.v = real(fa * tr.uv0[1] + fb * tr.uv1[1] + fg * tr.uv2[1]);
         outward = ld3(tr.n);
@@ -530,100 +579,105 @@ RTK_DEV V3<real> point_lighting(const SceneView<real>& sc, V3<real> p, V3<real> 
     return result;
 }
 
-// One sample: get_ray + ray_color (Camera.txt:177-238), iteratively.
-template <typename real, uint32_t FEAT, bool COUNT>
-RTK_DEV V3<real> trace_sample(const SceneView<real>& sc, const CameraRec<real>& cam, int i, int j, uint32_t& rng, Counters<COUNT>& cnt) {
-    // --- get_ray: sample_square draws y then x (g++ order), then the lens, then time
-    const real oy = rnd<real>(rng, cnt) - real(0.5);
-    const real ox = rnd<real>(rng, cnt) - real(0.5);
+// get_ray (Camera.txt:177-200) for sample L.s of pixel (i, j): seeds the sample's
+// RNG stream, draws sample_square (y then x, g++ order), the lens, then the time.
+template <typename real, bool COUNT>
+RTK_DEV void begin_sample(Lane<real>& L, const CameraRec<real>& cam, int i, int j, uint32_t seed_hash, Counters<COUNT>& cnt) {
+    cnt.inc(C_SAMPLES);
+    L.rng = pcg_hash(uint32_t(j * cam.width + i) + pcg_hash(uint32_t(L.s) + seed_hash));
+    const real oy = rnd<real>(L.rng, cnt) - real(0.5);
+    const real ox = rnd<real>(L.rng, cnt) - real(0.5);
     const V3<real> pixel_sample = ld3(cam.pixel00) + scale(real(i) + ox, ld3(cam.du)) + scale(real(j) + oy, ld3(cam.dv));
     V3<real> ro = ld3(cam.center);
     if (cam.defocus_angle > real(0)) {  // vec3.h:135-142
         real px, py;
         for (;;) {
-            py = real(-1) + real(2) * rnd<real>(rng, cnt);
-            px = real(-1) + real(2) * rnd<real>(rng, cnt);
+            py = real(-1) + real(2) * rnd<real>(L.rng, cnt);
+            px = real(-1) + real(2) * rnd<real>(L.rng, cnt);
             if (px * px + py * py + real(0) * real(0) < real(1)) break;
         }
         ro = ld3(cam.center) + scale(px, ld3(cam.disk_u)) + scale(py, ld3(cam.disk_v));
     }
-    V3<real> rd = pixel_sample - ro;
-    const real tm = rnd<real>(rng, cnt);
+    L.ro = ro;
+    L.rd = pixel_sample - ro;
+    L.tm = rnd<real>(L.rng, cnt);
+    L.radiance = mk(real(0), real(0), real(0));
+    L.throughput = mk(real(1), real(1), real(1));
+    L.depth = cam.max_depth;
+}
 
-    // --- ray_color
-    V3<real> radiance = mk(real(0), real(0), real(0));
-    V3<real> throughput = mk(real(1), real(1), real(1));
-    for (int depth = cam.max_depth; depth > 0; depth--) {
-        cnt.inc(C_SEGMENTS);
-        real t;
-        uint32_t best_pc;
-        closest_hit<real, FEAT, COUNT>(sc, ro, rd, tm, rng, cnt, t, best_pc);
-        if (best_pc == kNoHit) {  // Camera.txt:211-213
-            radiance = radiance + throughput * ld3(cam.background);
-            break;
-        }
-        cnt.inc(C_SURFACE);
-        Surface<real> sf;
-        make_surface<real, FEAT>(sc, best_pc, t, ro, rd, tm, sf);
-        const MaterialRec<real>& m = sc.materials[sf.material];
-
-        V3<real> attenuation, next_d;
-        bool scattered = true;
-        if (m.kind == RTK_MAT_LAMBERTIAN) {  // material.h:29-38
-            V3<real> dir = sf.normal + random_unit_vector<real>(rng, cnt);
-            if (near_zero(dir)) dir = sf.normal;
-            next_d = dir;
-            attenuation = material_color<real, FEAT>(sc, m, sf.u, sf.v, sf.p, cnt);
-        } else if (m.kind == RTK_MAT_METAL) {  // material.h:82-88
-            V3<real> refl = reflect(rd, sf.normal);
-            V3<real> fuzz = scale(m.param, random_unit_vector<real>(rng, cnt));
-            next_d = unit_vector(refl) + fuzz;
-            attenuation = ld3(m.albedo);
-            scattered = dot(next_d, sf.normal) > real(0);
-        } else if (m.kind == RTK_MAT_DIELECTRIC) {  // material.h:47-65
-            attenuation = mk(real(1), real(1), real(1));
-            const real ri = sf.front_face ? (real(1) / m.param) : m.param;
-            const V3<real> unit_d = unit_vector(rd);
-            const real cos_theta = rt_fmin(dot(-unit_d, sf.normal), real(1));
-            const real sin_theta = rt_sqrt(real(1) - cos_theta * cos_theta);
-            bool reflect_it = ri * sin_theta > real(1);
-            if (!reflect_it) {  // Schlick (material.h:69-74); the draw is skipped on total internal reflection
-                real r0 = (real(1) - ri) / (real(1) + ri);
-                r0 = r0 * r0;
-                const real refl = r0 + (real(1) - r0) * rt_pow(real(1) - cos_theta, real(5));
-                reflect_it = refl > rnd<real>(rng, cnt);
-            }
-            next_d = reflect_it ? reflect(unit_d, sf.normal) : refract(unit_d, sf.normal, ri);
-        } else if ((FEAT & F_EXOTIC_MAT) && m.kind == RTK_MAT_ISOTROPIC) {  // material.h:129-134
-            next_d = random_unit_vector<real>(rng, cnt);
-            attenuation = material_color<real, FEAT>(sc, m, sf.u, sf.v, sf.p, cnt);
-        } else if ((FEAT & F_EXOTIC_MAT) && m.kind == RTK_MAT_SPECULAR) {  // material.h:145-167
-            const V3<real> unit_d = unit_vector(rd);
-            const V3<real> refl = reflect(unit_d, sf.normal);
-            V3<real> diffuse = random_unit_vector<real>(rng, cnt);  // random_on_hemisphere, vec3.h:116-124
-            if (!(dot(diffuse, sf.normal) > real(0))) diffuse = -diffuse;
-            const real f = rt_pow(real(1) - dot(refl, unit_d), m.param);
-            V3<real> dir = scale(f, refl) + scale(real(1) - f, diffuse);
-            if (near_zero(dir)) dir = sf.normal;
-            next_d = dir;
-            attenuation = ld3(m.albedo);
-        } else {  // diffuse_light / emissive_light: emits, never scatters (material.h:99-101,116-118)
-            if (FEAT & F_EXOTIC_MAT) {
-                V3<real> emitted = material_color<real, FEAT>(sc, m, sf.u, sf.v, sf.p, cnt);
-                radiance = radiance + throughput * emitted;
-            }
-            break;
-        }
-        if (!scattered) break;  // Camera.txt:223-225 (emission of a scattering material is zero)
-        if ((FEAT & F_LIGHTS) && sc.n_lights > 0) {  // Camera.txt:228
-            V3<real> lighting = attenuation * point_lighting(sc, sf.p, sf.normal);
-            radiance = radiance + throughput * lighting;
-        }
-        throughput = throughput * attenuation;
-        ro = sf.p;
-        rd = next_d;
+// The traversal program ran to OP_END: the body of ray_color after world.hit
+// (Camera.txt:211-237), iteratively (radiance = sum of throughput * emission).
+// Returns true when the sample's path has ended.
+template <typename real, uint32_t FEAT, bool COUNT>
+RTK_DEV bool shade(Lane<real>& L, const Slot<real>* __restrict__ prog, const SceneView<real>& sc, const CameraRec<real>& cam, Counters<COUNT>& cnt) {
+    if (L.best_pc == kNoHit) {  // Camera.txt:211-213
+        L.radiance = L.radiance + L.throughput * ld3(cam.background);
+        return true;
     }
-    return radiance;
+    cnt.inc(C_SURFACE);
+    Surface<real> sf;
+    make_surface<real, FEAT>(prog, sc, L.best_pc, L.best_t, L.ro, L.rd, L.tm, sf);
+    const MaterialRec<real>& m = sc.materials[sf.material];
+    const V3<real> rd = L.rd;
+
+    V3<real> attenuation, next_d;
+    bool scattered = true;
+    if (m.kind == RTK_MAT_LAMBERTIAN) {  // material.h:29-38
+        V3<real> dir = sf.normal + random_unit_vector<real>(L.rng, cnt);
+        if (near_zero(dir)) dir = sf.normal;
+        next_d = dir;
+        attenuation = material_color<real, FEAT>(sc, m, sf.u, sf.v, sf.p, cnt);
+    } else if (m.kind == RTK_MAT_METAL) {  // material.h:82-88
+        V3<real> refl = reflect(rd, sf.normal);
+        V3<real> fuzz = scale(m.param, random_unit_vector<real>(L.rng, cnt));
+        next_d = unit_vector(refl) + fuzz;
+        attenuation = ld3(m.albedo);
+        scattered = dot(next_d, sf.normal) > real(0);
+    } else if (m.kind == RTK_MAT_DIELECTRIC) {  // material.h:47-65
+        attenuation = mk(real(1), real(1), real(1));
+        const real ri = sf.front_face ? (real(1) / m.param) : m.param;
+        const V3<real> unit_d = unit_vector(rd);
+        const real cos_theta = rt_fmin(dot(-unit_d, sf.normal), real(1));
+        const real sin_theta = rt_sqrt(real(1) - cos_theta * cos_theta);
+        bool reflect_it = ri * sin_theta > real(1);
+        if (!reflect_it) {  // Schlick (material.h:69-74); the draw is skipped on total internal reflection
+            real r0 = (real(1) - ri) / (real(1) + ri);
+            r0 = r0 * r0;
+            const real refl = r0 + (real(1) - r0) * rt_pow(real(1) - cos_theta, real(5));
+            reflect_it = refl > rnd<real>(L.rng, cnt);
+        }
+        next_d = reflect_it ? reflect(unit_d, sf.normal) : refract(unit_d, sf.normal, ri);
+    } else if ((FEAT & F_EXOTIC_MAT) && m.kind == RTK_MAT_ISOTROPIC) {  // material.h:129-134
+        next_d = random_unit_vector<real>(L.rng, cnt);
+        attenuation = material_color<real, FEAT>(sc, m, sf.u, sf.v, sf.p, cnt);
+    } else if ((FEAT & F_EXOTIC_MAT) && m.kind == RTK_MAT_SPECULAR) {  // material.h:145-167
+        const V3<real> unit_d = unit_vector(rd);
+        const V3<real> refl = reflect(unit_d, sf.normal);
+        V3<real> diffuse = random_unit_vector<real>(L.rng, cnt);  // random_on_hemisphere, vec3.h:116-124
+        if (!(dot(diffuse, sf.normal) > real(0))) diffuse = -diffuse;
+        const real f = rt_pow(real(1) - dot(refl, unit_d), m.param);
+        V3<real> dir = scale(f, refl) + scale(real(1) - f, diffuse);
+        if (near_zero(dir)) dir = sf.normal;
+        next_d = dir;
+        attenuation = ld3(m.albedo);
+    } else {  // diffuse_light / emissive_light: emits, never scatters (material.h:99-101,116-118)
+        if (FEAT & F_EXOTIC_MAT) {
+            V3<real> emitted = material_color<real, FEAT>(sc, m, sf.u, sf.v, sf.p, cnt);
+            L.radiance = L.radiance + L.throughput * emitted;
+        }
+        return true;
+    }
+    if (!scattered) return true;  // Camera.txt:223-225 (emission of a scattering material is zero)
+    if ((FEAT & F_LIGHTS) && sc.n_lights > 0) {  // Camera.txt:228
+        V3<real> lighting = attenuation * point_lighting(sc, sf.p, sf.normal);
+        L.radiance = L.radiance + L.throughput * lighting;
+    }
+    L.throughput = L.throughput * attenuation;
+    L.ro = sf.p;
+    L.rd = next_d;
+    L.depth -= 1;
+    return L.depth <= 0;  // Camera.txt:205-206: the next ray_color call returns black
 }
 
 RTK_DEV uint8_t to_byte(double x) {  // Camera.txt:29-34,77-83
@@ -633,52 +687,134 @@ RTK_DEV uint8_t to_byte(double x) {  // Camera.txt:29-34,77-83
 }
 
 // ------------------------------------------------------------------ kernel ----
-// One wave = one 8x8 tile; lane l owns pixel (l & 7, l >> 3) of the tile and
-// walks its samples in order, so the per-pixel sum has the reference's
-// summation order (Camera.txt:70-73).
-template <typename real, uint32_t FEAT, bool COUNT>
-__global__ __launch_bounds__(256) void rtk_render_kernel(SceneView<real> sc, CameraRec<real> cam, TileMap tmap, uint32_t seed, real* __restrict__ out_linear,
-                                                          uint8_t* __restrict__ out_rgb8, unsigned long long* __restrict__ counters) {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int local_tile = blockIdx.x * 4 + wave;
-    const int tile = local_tile * tmap.n_ranks + tmap.rank;
-    const bool tile_ok = local_tile < tmap.n_tiles_local && tile < tmap.tiles_x * tmap.tiles_y;
-    const int tx = tile_ok ? tile % tmap.tiles_x : 0, ty = tile_ok ? tile / tmap.tiles_x : 0;
-    const int i = tx * 8 + (lane & 7), j = ty * 8 + (lane >> 3);
-    const bool active = tile_ok && i < cam.width && j < cam.height;
+// Persistent waves + a wave-level ballot scheduler.
+//
+// Each workgroup first stages the traversal program from HBM into LDS with
+// coalesced 16-byte loads (when IN_LDS: the host checked it fits); then every
+// wave repeatedly pulls the next 8x8 tile of this rank from an atomic counter.
+// Lane l owns pixel (l & 7, l >> 3) of the tile and walks its samples in order,
+// so the per-pixel sum has the reference's summation order (Camera.txt:70-73) and
+// the image does not depend on which wave, workgroup or GPU rendered a tile.
+//
+// Paths have 1..max_depth segments and rays visit 1..100+ program records, so a
+// lock-step "all lanes trace, then all lanes shade" loop leaves ~90 % of the
+// lanes idle.  Instead each lane is a small state machine (Lane<real>) and in
+// every iteration the wave VOTES (v_cmp + s_bcnt1 on the 64-bit ballots) on which
+// kind of work has the most lanes ready -- box test, sphere test, another record
+// kind, or shade/regenerate -- and runs only that, under a wave-uniform branch.
+// Lanes waiting for a different kind keep their state and join a later vote; a
+// lane whose path ends starts its next sample in the same shade step, so nobody
+// waits for the longest path in the wave.  Scheduling changes only the
+// interleaving between lanes, never a lane's own arithmetic, so the image is
+// bit-identical to a lock-step execution.
+enum Want : int { W_DONE = 0, W_BOX = 1, W_SPHERE = 2, W_OTHER = 3, W_SHADE = 4 };
 
+template <typename real, uint32_t FEAT, bool COUNT, bool IN_LDS>
+__global__ __launch_bounds__(768) void rtk_render_kernel(SceneView<real> sc, CameraRec<real> cam, TileMap tmap, uint32_t seed, real* __restrict__ out_linear,
+                                                          uint8_t* __restrict__ out_rgb8, unsigned long long* __restrict__ counters,
+                                                          unsigned int* __restrict__ tile_counter) {
+    extern __shared__ __align__(16) unsigned char lds_program[];
+    const Slot<real>* prog = sc.program;
+    if constexpr (IN_LDS) {
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(sc.program);
+        uint4* dst = reinterpret_cast<uint4*>(lds_program);
+        const int n16 = sc.n_slots * int(sizeof(Slot<real>) / 16);
+        for (int k = threadIdx.x; k < n16; k += blockDim.x) dst[k] = src[k];
+        __syncthreads();
+        prog = reinterpret_cast<const Slot<real>*>(lds_program);
+    }
+    const int lane = threadIdx.x & 63;
+    const uint32_t seed_hash = pcg_hash(seed);
+    const int n_tiles_total = tmap.tiles_x * tmap.tiles_y;
     Counters<COUNT> cnt;
     cnt.clear();
-    V3<real> sum = mk(real(0), real(0), real(0));
-    if (active) {
-        const uint32_t pixel = uint32_t(j * cam.width + i);
-        const uint32_t seed_hash = pcg_hash(seed);
-        for (int s = 0; s < cam.spp; s++) {
-            uint32_t rng = pcg_hash(pixel + pcg_hash(uint32_t(s) + seed_hash));
-            cnt.inc(C_SAMPLES);
-            sum = sum + trace_sample<real, FEAT, COUNT>(sc, cam, i, j, rng, cnt);
+    for (;;) {
+        unsigned int fetched = 0;
+        if (lane == 0) fetched = atomicAdd(tile_counter, 1u);
+        const int local_tile = int(__builtin_amdgcn_readfirstlane(fetched));
+        if (local_tile >= tmap.n_tiles_local) break;
+        const int tile = local_tile * tmap.n_ranks + tmap.rank;
+        const bool tile_ok = tile < n_tiles_total;
+        const int tx = tile_ok ? tile % tmap.tiles_x : 0, ty = tile_ok ? tile / tmap.tiles_x : 0;
+        const int i = tx * 8 + (lane & 7), j = ty * 8 + (lane >> 3);
+        const bool active = tile_ok && i < cam.width && j < cam.height;
+
+        Lane<real> L;
+        L.sum = mk(real(0), real(0), real(0));
+        L.s = 0;
+        L.pc = 0;
+        bool alive = active && cam.spp > 0;
+        if (alive) {
+            begin_sample(L, cam, i, j, seed_hash, cnt);
+            if (L.depth > 0) {
+                begin_segment(L, cnt);
+            } else {  // max_depth == 0: every sample is black (Camera.txt:205-206)
+                alive = false;
+            }
         }
-        sum = scale(cam.samples_scale, sum);  // Camera.txt:74
-    }
-    if (tmap.compact) {
-        if (tile_ok && out_linear) {
-            real* base = out_linear + size_t(local_tile) * 192 + lane;
-            base[0] = sum.x;
-            base[64] = sum.y;
-            base[128] = sum.z;
+        Slot<real> cur = prog[L.pc];
+        for (;;) {
+            const uint32_t kind = cur.kind_payload & 15u;
+            const int want = !alive ? W_DONE : (kind == OP_BOX ? W_BOX : (kind == OP_SPHERE ? W_SPHERE : (kind == OP_END ? W_SHADE : W_OTHER)));
+            const unsigned long long m_box = __ballot(want == W_BOX);
+            const unsigned long long m_sph = __ballot(want == W_SPHERE);
+            const unsigned long long m_oth = __ballot(want == W_OTHER);
+            const unsigned long long m_shd = __ballot(want == W_SHADE);
+            if ((m_box | m_sph | m_oth | m_shd) == 0ull) break;
+            const int n_box = __popcll(m_box), n_sph = __popcll(m_sph), n_oth = __popcll(m_oth), n_shd = __popcll(m_shd);
+            if (n_box >= n_sph && n_box >= n_oth && n_box >= n_shd) {
+                if (want == W_BOX) {
+                    step_box(L, cur, cnt);
+                    cur = prog[L.pc];
+                }
+            } else if (n_sph >= n_oth && n_sph >= n_shd) {
+                if (want == W_SPHERE) {
+                    step_sphere(L, cur, cnt);
+                    cur = prog[L.pc];
+                }
+            } else if (n_shd >= n_oth) {
+                if (want == W_SHADE) {
+                    if (shade<real, FEAT, COUNT>(L, prog, sc, cam, cnt)) {  // path ended: pixel_color += ray_color (Camera.txt:72)
+                        L.sum = L.sum + L.radiance;
+                        L.s += 1;
+                        if (L.s < cam.spp) {
+                            begin_sample(L, cam, i, j, seed_hash, cnt);
+                        } else {
+                            alive = false;
+                        }
+                    }
+                    if (alive) {
+                        begin_segment(L, cnt);
+                        cur = prog[0];
+                    }
+                }
+            } else {
+                if (want == W_OTHER) {
+                    step_other<real, FEAT, COUNT>(L, prog + L.pc, sc, cnt);
+                    cur = prog[L.pc];
+                }
+            }
         }
-    } else if (active) {
-        const size_t idx = (size_t(j) * cam.width + i) * 3;
-        if (out_linear) {
-            out_linear[idx] = sum.x;
-            out_linear[idx + 1] = sum.y;
-            out_linear[idx + 2] = sum.z;
-        }
-        if (out_rgb8) {
-            out_rgb8[idx] = to_byte(double(sum.x));
-            out_rgb8[idx + 1] = to_byte(double(sum.y));
-            out_rgb8[idx + 2] = to_byte(double(sum.z));
+        const V3<real> sum = scale(cam.samples_scale, L.sum);  // Camera.txt:74
+        if (tmap.compact) {
+            if (out_linear) {
+                real* base = out_linear + size_t(local_tile) * 192 + lane;
+                base[0] = sum.x;
+                base[64] = sum.y;
+                base[128] = sum.z;
+            }
+        } else if (active) {
+            const size_t idx = (size_t(j) * cam.width + i) * 3;
+            if (out_linear) {
+                out_linear[idx] = sum.x;
+                out_linear[idx + 1] = sum.y;
+                out_linear[idx + 2] = sum.z;
+            }
+            if (out_rgb8) {
+                out_rgb8[idx] = to_byte(double(sum.x));
+                out_rgb8[idx + 1] = to_byte(double(sum.y));
+                out_rgb8[idx + 2] = to_byte(double(sum.z));
+            }
         }
     }
     if constexpr (COUNT) {
@@ -718,26 +854,80 @@ __global__ __launch_bounds__(256) void rtk_unpermute_kernel(const real* __restri
 }
 
 // ------------------------------------------------------------------ launchers --
-template <typename real, uint32_t FEAT, bool COUNT>
+constexpr int kLdsBytesPerCU = 160 * 1024;
+constexpr int kMaxWavesPerBlock = 12;  // __launch_bounds__(768)
+
+// Geometry of a persistent launch: waves per workgroup and workgroups per CU so
+// that (a) the register-limited wave count per CU is reached and (b) every
+// resident workgroup's LDS copy of the program fits.
+template <typename Kernel>
+static hipError_t plan_launch(Kernel kernel, size_t lds_bytes, int n_tiles, int& blocks, int& threads) {
+    int device = 0, cus = 256, waves_per_cu = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    if (lds_bytes > 64 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
+        if (e != hipSuccess) return e;
+    }
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves_per_cu, kernel, 64, 0);  // register-limited waves per CU
+    if (e != hipSuccess) return e;
+    if (waves_per_cu < 4) waves_per_cu = 4;
+    if (waves_per_cu > 32) waves_per_cu = 32;
+    int blocks_per_cu = (waves_per_cu + kMaxWavesPerBlock - 1) / kMaxWavesPerBlock;
+    if (lds_bytes > 0) {
+        const int by_lds = int(kLdsBytesPerCU / lds_bytes);
+        if (by_lds < 1) return hipErrorInvalidValue;
+        if (blocks_per_cu > by_lds) blocks_per_cu = by_lds;
+    }
+    int waves_per_block = waves_per_cu / blocks_per_cu;
+    if (waves_per_block > kMaxWavesPerBlock) waves_per_block = kMaxWavesPerBlock;
+    if (waves_per_block < 1) waves_per_block = 1;
+    threads = waves_per_block * 64;
+    blocks = cus * blocks_per_cu;
+    const int needed = (n_tiles + waves_per_block - 1) / waves_per_block;
+    if (blocks > needed) blocks = needed;
+    if (blocks < 1) blocks = 1;
+    return hipSuccess;
+}
+
+template <typename real, uint32_t FEAT, bool COUNT, bool IN_LDS>
 static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>& cam, const TileMap& tmap, uint32_t seed, void* out_linear, uint8_t* out_rgb8,
-                             unsigned long long* counters, hipStream_t stream) {
-    const int blocks = (tmap.n_tiles_local + 3) / 4;
-    if (blocks <= 0) return hipSuccess;
-    rtk_render_kernel<real, FEAT, COUNT><<<dim3(blocks), dim3(256), 0, stream>>>(sc, cam, tmap, seed, static_cast<real*>(out_linear), out_rgb8, counters);
+                             unsigned long long* counters, unsigned int* tile_counter, hipStream_t stream) {
+    if (tmap.n_tiles_local <= 0) return hipSuccess;
+    auto kernel = rtk_render_kernel<real, FEAT, COUNT, IN_LDS>;
+    const size_t lds = IN_LDS ? size_t(sc.n_slots) * sizeof(Slot<real>) : 0;
+    int blocks = 0, threads = 0;
+    hipError_t e = plan_launch(kernel, lds, tmap.n_tiles_local, blocks, threads);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(tile_counter, 0, sizeof(unsigned int), stream);
+    if (e != hipSuccess) return e;
+    kernel<<<dim3(blocks), dim3(threads), lds, stream>>>(sc, cam, tmap, seed, static_cast<real*>(out_linear), out_rgb8, counters, tile_counter);
     return hipGetLastError();
 }
 
 template <typename real>
-hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>& cam, const TileMap& tmap, uint32_t seed, uint32_t features, bool count,
-                         void* out_linear, uint8_t* out_rgb8, unsigned long long* counters, hipStream_t stream) {
-    if (count) return launch_one<real, kFeatAll, true>(sc, cam, tmap, seed, out_linear, out_rgb8, counters, stream);
-    if (features == kFeatLean) return launch_one<real, kFeatLean, false>(sc, cam, tmap, seed, out_linear, out_rgb8, counters, stream);
-    return launch_one<real, kFeatAll, false>(sc, cam, tmap, seed, out_linear, out_rgb8, counters, stream);
+bool program_fits_lds(const SceneView<real>& sc) {
+    return size_t(sc.n_slots) * sizeof(Slot<real>) <= size_t(kLdsBytesPerCU);
 }
-template hipError_t launch_render<double>(const SceneView<double>&, const CameraRec<double>&, const TileMap&, uint32_t, uint32_t, bool, void*, uint8_t*,
-                                          unsigned long long*, hipStream_t);
-template hipError_t launch_render<float>(const SceneView<float>&, const CameraRec<float>&, const TileMap&, uint32_t, uint32_t, bool, void*, uint8_t*,
-                                         unsigned long long*, hipStream_t);
+
+template <typename real>
+hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>& cam, const TileMap& tmap, uint32_t seed, uint32_t features, bool count,
+                         bool allow_lds, void* out_linear, uint8_t* out_rgb8, unsigned long long* counters, unsigned int* tile_counter, hipStream_t stream) {
+    const bool lds = allow_lds && program_fits_lds(sc);
+    if (count) return launch_one<real, kFeatAll, true, false>(sc, cam, tmap, seed, out_linear, out_rgb8, counters, tile_counter, stream);
+    if (features == kFeatLean)
+        return lds ? launch_one<real, kFeatLean, false, true>(sc, cam, tmap, seed, out_linear, out_rgb8, counters, tile_counter, stream)
+                   : launch_one<real, kFeatLean, false, false>(sc, cam, tmap, seed, out_linear, out_rgb8, counters, tile_counter, stream);
+    return lds ? launch_one<real, kFeatAll, false, true>(sc, cam, tmap, seed, out_linear, out_rgb8, counters, tile_counter, stream)
+               : launch_one<real, kFeatAll, false, false>(sc, cam, tmap, seed, out_linear, out_rgb8, counters, tile_counter, stream);
+}
+template hipError_t launch_render<double>(const SceneView<double>&, const CameraRec<double>&, const TileMap&, uint32_t, uint32_t, bool, bool, void*, uint8_t*,
+                                          unsigned long long*, unsigned int*, hipStream_t);
+template hipError_t launch_render<float>(const SceneView<float>&, const CameraRec<float>&, const TileMap&, uint32_t, uint32_t, bool, bool, void*, uint8_t*,
+                                         unsigned long long*, unsigned int*, hipStream_t);
+template bool program_fits_lds<double>(const SceneView<double>&);
+template bool program_fits_lds<float>(const SceneView<float>&);
 
 template <typename real>
 hipError_t launch_unpermute(const void* gathered, int width, int height, int n_ranks, long long tiles_per_rank, void* out_linear, uint8_t* out_rgb8,
@@ -752,10 +942,14 @@ hipError_t launch_unpermute(const void* gathered, int width, int height, int n_r
 template hipError_t launch_unpermute<double>(const void*, int, int, int, long long, void*, uint8_t*, hipStream_t);
 template hipError_t launch_unpermute<float>(const void*, int, int, int, long long, void*, uint8_t*, hipStream_t);
 
-const char* render_kernel_name(bool f64, uint32_t features, bool count) {
-    if (count) return f64 ? "rtk_render_kernel<double, 127u, true>" : "rtk_render_kernel<float, 127u, true>";
-    if (features == kFeatLean) return f64 ? "rtk_render_kernel<double, 0u, false>" : "rtk_render_kernel<float, 0u, false>";
-    return f64 ? "rtk_render_kernel<double, 127u, false>" : "rtk_render_kernel<float, 127u, false>";
+const char* render_kernel_name(bool f64, uint32_t features, bool count, bool lds) {
+    if (count) return f64 ? "rtk_render_kernel<double, 127u, true, false>" : "rtk_render_kernel<float, 127u, true, false>";
+    if (features == kFeatLean) {
+        if (lds) return f64 ? "rtk_render_kernel<double, 0u, false, true>" : "rtk_render_kernel<float, 0u, false, true>";
+        return f64 ? "rtk_render_kernel<double, 0u, false, false>" : "rtk_render_kernel<float, 0u, false, false>";
+    }
+    if (lds) return f64 ? "rtk_render_kernel<double, 127u, false, true>" : "rtk_render_kernel<float, 127u, false, true>";
+    return f64 ? "rtk_render_kernel<double, 127u, false, false>" : "rtk_render_kernel<float, 127u, false, false>";
 }
 
 }  // namespace rtk

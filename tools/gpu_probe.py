@@ -19,6 +19,8 @@ for name, W, H, spp, depth in cases:
         t0 = time.time()
         g, g8, gc = r.render_host(cam, real_mode=mode, count=True)
         g2, g28, _ = r.render_host(cam, real_mode=mode, count=False)
+        g3, _, _ = r.render_host(cam, real_mode=mode, count=False, variant=1)
+        assert np.array_equal(g2, g3), "LDS and global-memory program variants disagree"
         dt = time.time() - t0
         d = g - ref
         bad = {k: (gc[k], oc[k]) for k in gc if gc[k] != oc[k]}

@@ -471,8 +471,19 @@ struct rtk_ctx {
     // small ring so that back-to-back launches on a stream never share one.
     unsigned int* tile_counters = nullptr;
     unsigned int next_counter = 0;
+    // Camera records in device memory (the kernel reads them with scalar loads),
+    // same ring discipline; the host copies stay alive until the async copy ran.
+    unsigned char* d_cameras = nullptr;
+    // Partial-sum workspace [work item][3][64] reals, grown on demand and reused by
+    // successive launches (they are ordered on the caller's stream).
+    void* d_partial = nullptr;
+    size_t partial_bytes = 0;
+    std::vector<CameraRec<double>> h_cameras64;
+    std::vector<CameraRec<float>> h_cameras32;
 };
 constexpr unsigned int kCounterRing = 256;
+constexpr size_t kCameraStride = 256;
+static_assert(sizeof(CameraRec<double>) <= kCameraStride, "camera stride");
 
 extern "C" {
 
@@ -496,10 +507,14 @@ int rtk_init(int device, rtk_ctx** out_ctx) {
     auto* ctx = new rtk_ctx;
     ctx->device = device;
     hipError_t me = hipMalloc(reinterpret_cast<void**>(&ctx->tile_counters), kCounterRing * sizeof(unsigned int));
+    if (me == hipSuccess) me = hipMalloc(reinterpret_cast<void**>(&ctx->d_cameras), kCounterRing * kCameraStride);
     if (me != hipSuccess) {
+        if (ctx->tile_counters) (void)hipFree(ctx->tile_counters);
         delete ctx;
-        return fail(RTK_ERR_HIP, "hipMalloc(tile counters) failed: %s", hipGetErrorString(me));
+        return fail(RTK_ERR_HIP, "hipMalloc(launch state) failed: %s", hipGetErrorString(me));
     }
+    ctx->h_cameras64.resize(kCounterRing);
+    ctx->h_cameras32.resize(kCounterRing);
     *out_ctx = ctx;
     return RTK_OK;
 }
@@ -510,6 +525,8 @@ int rtk_destroy(rtk_ctx* ctx) {
     ctx->scene64.release();
     ctx->scene32.release();
     if (ctx->tile_counters) (void)hipFree(ctx->tile_counters);
+    if (ctx->d_cameras) (void)hipFree(ctx->d_cameras);
+    if (ctx->d_partial) (void)hipFree(ctx->d_partial);
     delete ctx;
     return RTK_OK;
 }
@@ -566,17 +583,47 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
     tm.n_ranks = opts->n_ranks;
     tm.n_tiles_local = int32_t(rtk_tiles_per_rank(cam->image_width, cam->image_height, opts->n_ranks));
     tm.compact = opts->n_ranks > 1 ? 1 : 0;
+    // Split every pixel's samples into chunks so that no lane is stuck with a whole
+    // heavy pixel (the longest pixel would otherwise bound the kernel): about 8
+    // samples per chunk, at most 16 chunks.
+    int n_chunks = cam->samples_per_pixel / 8;
+    n_chunks = n_chunks < 1 ? 1 : (n_chunks > 16 ? 16 : n_chunks);
+    if (opts->variant & 2) n_chunks = 1;  // variant bit 1: one lane per pixel for all samples (A/B)
+    tm.chunk_spp = (cam->samples_per_pixel + n_chunks - 1) / n_chunks;
+    tm.n_chunks = (cam->samples_per_pixel + tm.chunk_spp - 1) / tm.chunk_spp;
+    const size_t elem = opts->real_mode == RTK_REAL_F64 ? sizeof(double) : sizeof(float);
+    const size_t need = size_t(tm.n_tiles_local) * tm.n_chunks * 192 * elem;
+    if (need > ctx->partial_bytes) {
+        if (ctx->d_partial) {
+            RTK_HIP(hipDeviceSynchronize());  // earlier launches may still read the old workspace
+            RTK_HIP(hipFree(ctx->d_partial));
+            ctx->d_partial = nullptr;
+            ctx->partial_bytes = 0;
+        }
+        RTK_HIP(hipMalloc(&ctx->d_partial, need));
+        ctx->partial_bytes = need;
+    }
     hipStream_t stream = static_cast<hipStream_t>(opts->stream);
     auto* counters = reinterpret_cast<unsigned long long*>(d_counters);
-    unsigned int* tile_counter = ctx->tile_counters + (ctx->next_counter++ % kCounterRing);
-    const bool allow_lds = opts->variant != 1;  // variant 1: keep the program in global memory (A/B)
+    const unsigned int slot = ctx->next_counter++ % kCounterRing;
+    unsigned int* tile_counter = ctx->tile_counters + slot;
+    unsigned char* d_cam = ctx->d_cameras + slot * kCameraStride;
+    const bool allow_lds = (opts->variant & 1) == 0;  // variant bit 0: keep the program in global memory (A/B)
+    const uint32_t diag = uint32_t(opts->variant) & 0xF0u;  // bits 4..7: timing ablations used by tools/ only
     hipError_t e;
-    if (opts->real_mode == RTK_REAL_F64)
-        e = launch_render<double>(ctx->scene64.view, to_device_camera<double>(*cam), tm, opts->seed, ctx->features, opts->count_work != 0, allow_lds,
-                                  d_linear, d_rgb8, counters, tile_counter, stream);
-    else
-        e = launch_render<float>(ctx->scene32.view, to_device_camera<float>(*cam), tm, opts->seed, ctx->features, opts->count_work != 0, allow_lds,
-                                 d_linear, d_rgb8, counters, tile_counter, stream);
+    if (opts->real_mode == RTK_REAL_F64) {
+        ctx->h_cameras64[slot] = to_device_camera<double>(*cam);
+        RTK_HIP(hipMemcpyAsync(d_cam, &ctx->h_cameras64[slot], sizeof(CameraRec<double>), hipMemcpyHostToDevice, stream));
+        e = launch_render<double>(ctx->scene64.view, reinterpret_cast<const CameraRec<double>*>(d_cam), tm, opts->seed, ctx->features,
+                                  opts->count_work != 0, allow_lds, diag, ctx->d_partial, counters, tile_counter, stream);
+        if (e == hipSuccess) e = launch_resolve<double>(ctx->d_partial, tm, cam->image_width, cam->image_height, cam->pixel_samples_scale, d_linear, d_rgb8, stream);
+    } else {
+        ctx->h_cameras32[slot] = to_device_camera<float>(*cam);
+        RTK_HIP(hipMemcpyAsync(d_cam, &ctx->h_cameras32[slot], sizeof(CameraRec<float>), hipMemcpyHostToDevice, stream));
+        e = launch_render<float>(ctx->scene32.view, reinterpret_cast<const CameraRec<float>*>(d_cam), tm, opts->seed, ctx->features,
+                                 opts->count_work != 0, allow_lds, diag, ctx->d_partial, counters, tile_counter, stream);
+        if (e == hipSuccess) e = launch_resolve<float>(ctx->d_partial, tm, cam->image_width, cam->image_height, cam->pixel_samples_scale, d_linear, d_rgb8, stream);
+    }
     if (e != hipSuccess) return fail(RTK_ERR_HIP, "render kernel launch failed: %s", hipGetErrorString(e));
     return RTK_OK;
 }
@@ -656,7 +703,7 @@ int rtk_scene_info(rtk_ctx* ctx, int32_t* n_program_ops, int64_t* bytes_f64, int
 const char* rtk_kernel_name(rtk_ctx* ctx, int real_mode, int variant) {
     if (!ctx || !ctx->has_scene) return "";
     const bool f64 = real_mode == RTK_REAL_F64;
-    const bool lds = variant != 1 && (f64 ? program_fits_lds(ctx->scene64.view) : program_fits_lds(ctx->scene32.view));
+    const bool lds = (variant & 1) == 0 && (f64 ? program_fits_lds(ctx->scene64.view) : program_fits_lds(ctx->scene32.view));
     return render_kernel_name(f64, ctx->features, false, lds);
 }
 

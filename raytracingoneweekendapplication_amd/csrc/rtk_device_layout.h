@@ -169,9 +169,14 @@ struct SceneView {  // device pointers, passed to the kernel by value
 };
 
 struct TileMap {  // which tiles this launch renders and where the pixels go
-    int32_t tiles_x, tiles_y, n_tiles_local;  // tiles are pulled by persistent waves from an atomic counter
+    int32_t tiles_x, tiles_y, n_tiles_local;
     int32_t rank, n_ranks;
-    int32_t compact;  // 1: write [local_tile][3][64] reals, 0: write the row-major image
+    int32_t compact;  // resolve output: 1 = this rank's [local_tile][3][64] buffer, 0 = the row-major image
+    // Work items pulled by the persistent waves from an atomic counter: item = local_tile * n_chunks + chunk,
+    // chunk c covers samples [c * chunk_spp, min(spp, (c+1) * chunk_spp)) of each of the tile's 64 pixels.
+    // The render kernel writes one partial sum per (item, pixel) into partial[item][3][64]; the resolve
+    // kernel adds a pixel's chunks in index order (deterministic, independent of scheduling and GPU count).
+    int32_t n_chunks, chunk_spp;
 };
 
 // Indices into the uint64 work-counter block (same order as rtk_work_counters).

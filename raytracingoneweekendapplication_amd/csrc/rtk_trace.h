@@ -12,11 +12,17 @@ namespace rtk {
 // kernel instantiation (kFeatLean or kFeatAll); `count` selects the
 // work-counting instantiation (always the full-feature kernel).  tile_counter is
 // a device word the persistent waves pull tile indices from (zeroed on `stream`
-// before the launch).
+// before the launch); d_cam points at the camera record in device memory.  `diag`
+// bits 16/32 are timing ablations for tools/ (wrong images, never set by the product).
 template <typename real>
-hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>& cam, const TileMap& tmap, uint32_t seed, uint32_t features, bool count,
-                         bool allow_lds, void* out_linear, uint8_t* out_rgb8, unsigned long long* counters, unsigned int* tile_counter,
+hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>* d_cam, const TileMap& tmap, uint32_t seed, uint32_t features, bool count,
+                         bool allow_lds, uint32_t diag, void* partial, unsigned long long* counters, unsigned int* tile_counter,
                          hipStream_t stream);
+
+// Partial sums [item][3][64] -> the row-major image (+ bytes) or this rank's compact tile buffer.
+template <typename real>
+hipError_t launch_resolve(const void* partial, const TileMap& tmap, int width, int height, double samples_scale, void* out_linear, uint8_t* out_rgb8,
+                          hipStream_t stream);
 
 // Whether the traversal program of `sc` can be staged in one CU's LDS.
 template <typename real>

@@ -709,10 +709,19 @@ RTK_DEV uint8_t to_byte(double x) {  // Camera.txt:29-34,77-83
 // bit-identical to a lock-step execution.
 enum Want : int { W_DONE = 0, W_BOX = 1, W_SPHERE = 2, W_OTHER = 3, W_SHADE = 4 };
 
+// A finished (pixel, chunk): its sum of ray_color values goes to partial[item][3][64].
+template <typename real>
+RTK_DEV void store_partial(real* __restrict__ partial, int item, int pix, V3<real> sum) {
+    real* base = partial + size_t(item) * 192 + pix;
+    base[0] = sum.x;
+    base[64] = sum.y;
+    base[128] = sum.z;
+}
+
 template <typename real, uint32_t FEAT, bool COUNT, bool IN_LDS>
-__global__ __launch_bounds__(768) void rtk_render_kernel(SceneView<real> sc, CameraRec<real> cam, TileMap tmap, uint32_t seed, real* __restrict__ out_linear,
-                                                          uint8_t* __restrict__ out_rgb8, unsigned long long* __restrict__ counters,
-                                                          unsigned int* __restrict__ tile_counter) {
+__global__ __launch_bounds__(768) void rtk_render_kernel(SceneView<real> sc, const CameraRec<real>* __restrict__ cam_ptr, TileMap tmap, uint32_t seed,
+                                                          real* __restrict__ partial, unsigned long long* __restrict__ counters,
+                                                          unsigned int* __restrict__ tile_counter, uint32_t diag) {
     extern __shared__ __align__(16) unsigned char lds_program[];
     const Slot<real>* prog = sc.program;
     if constexpr (IN_LDS) {
@@ -723,98 +732,130 @@ __global__ __launch_bounds__(768) void rtk_render_kernel(SceneView<real> sc, Cam
         __syncthreads();
         prog = reinterpret_cast<const Slot<real>*>(lds_program);
     }
+    // The camera lives in device memory and is read with scalar loads where it is
+    // used (once per sample); as a by-value argument it would sit in registers for
+    // the whole kernel.
+    const CameraRec<real>& cam = *cam_ptr;
     const int lane = threadIdx.x & 63;
     const uint32_t seed_hash = pcg_hash(seed);
     const int n_tiles_total = tmap.tiles_x * tmap.tiles_y;
+    const int width = cam.width, height = cam.height, spp = cam.spp;
+    const uint32_t end_pc = uint32_t(sc.n_slots - 1);
     Counters<COUNT> cnt;
     cnt.clear();
-    for (;;) {
-        unsigned int fetched = 0;
-        if (lane == 0) fetched = atomicAdd(tile_counter, 1u);
-        const int local_tile = int(__builtin_amdgcn_readfirstlane(fetched));
-        if (local_tile >= tmap.n_tiles_local) break;
-        const int tile = local_tile * tmap.n_ranks + tmap.rank;
-        const bool tile_ok = tile < n_tiles_total;
-        const int tx = tile_ok ? tile % tmap.tiles_x : 0, ty = tile_ok ? tile / tmap.tiles_x : 0;
-        const int i = tx * 8 + (lane & 7), j = ty * 8 + (lane >> 3);
-        const bool active = tile_ok && i < cam.width && j < cam.height;
 
-        Lane<real> L;
-        L.sum = mk(real(0), real(0), real(0));
-        L.s = 0;
-        L.pc = 0;
-        bool alive = active && cam.spp > 0;
-        if (alive) {
-            begin_sample(L, cam, i, j, seed_hash, cnt);
-            if (L.depth > 0) {
-                begin_segment(L, cnt);
-            } else {  // max_depth == 0: every sample is black (Camera.txt:205-206)
-                alive = false;
+    // Wave-uniform hand-out state: pixels of work item `refill_item` from
+    // `refill_next` on have not been given to a lane yet.
+    const int n_items = tmap.n_tiles_local * tmap.n_chunks;
+    int refill_item = 0, refill_next = 64;
+    bool exhausted = false;
+
+    Lane<real> L;
+    L.pc = end_pc;
+    L.sum = mk(real(0), real(0), real(0));
+    L.s = 0;
+    bool alive = false;               // this lane currently owns a (pixel, chunk)
+    int my_item = 0, my_pix = 0, px_i = 0, px_j = 0, s_end = 0;
+
+    for (;;) {
+        // ---- regeneration at pixel granularity: idle lanes take the next pixels of
+        // the wave's current work item (a tile x a chunk of the samples); when it is
+        // used up the wave pulls another item from the rank-wide counter.  A (pixel,
+        // chunk) belongs to exactly one lane, which walks its samples in order.
+        unsigned long long m_idle = __ballot(!alive);
+        while (m_idle != 0ull && !exhausted) {
+            if (refill_next >= 64) {
+                unsigned int fetched = 0;
+                if (lane == 0) fetched = atomicAdd(tile_counter, 1u);
+                const int t = int(__builtin_amdgcn_readfirstlane(fetched));
+                if (t >= n_items) {
+                    exhausted = true;
+                    break;
+                }
+                refill_item = t;
+                refill_next = 0;
             }
+            const int avail = 64 - refill_next;
+            const int rank_in_idle = int(__builtin_amdgcn_mbcnt_hi(uint32_t(m_idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m_idle), 0u)));
+            if (!alive && rank_in_idle < avail) {
+                my_item = refill_item;
+                my_pix = refill_next + rank_in_idle;
+                const int local_tile = refill_item / tmap.n_chunks, chunk = refill_item % tmap.n_chunks;
+                const int tile = local_tile * tmap.n_ranks + tmap.rank;
+                px_i = (tile % tmap.tiles_x) * 8 + (my_pix & 7);
+                px_j = (tile / tmap.tiles_x) * 8 + (my_pix >> 3);
+                const int s_begin = chunk * tmap.chunk_spp;
+                s_end = s_begin + tmap.chunk_spp < spp ? s_begin + tmap.chunk_spp : spp;
+                if (tile < n_tiles_total && px_i < width && px_j < height && s_begin < s_end) {
+                    alive = true;
+                    L.sum = mk(real(0), real(0), real(0));
+                    L.s = s_begin;
+                    begin_sample(L, cam, px_i, px_j, seed_hash, cnt);
+                    if (L.depth > 0) begin_segment(L, cnt);
+                    else L.pc = end_pc;  // max_depth == 0: ray_color returns black at once (Camera.txt:205-206)
+                }
+            }
+            const int n_idle = int(__builtin_popcountll(m_idle));
+            refill_next += n_idle < avail ? n_idle : avail;
+            m_idle = __ballot(!alive);
+            if (n_idle <= avail) break;  // every idle lane was offered a pixel this round (some fell outside the image)
         }
-        Slot<real> cur = prog[L.pc];
-        for (;;) {
-            const uint32_t kind = cur.kind_payload & 15u;
-            const int want = !alive ? W_DONE : (kind == OP_BOX ? W_BOX : (kind == OP_SPHERE ? W_SPHERE : (kind == OP_END ? W_SHADE : W_OTHER)));
-            const unsigned long long m_box = __ballot(want == W_BOX);
-            const unsigned long long m_sph = __ballot(want == W_SPHERE);
-            const unsigned long long m_oth = __ballot(want == W_OTHER);
-            const unsigned long long m_shd = __ballot(want == W_SHADE);
-            if ((m_box | m_sph | m_oth | m_shd) == 0ull) break;
-            const int n_box = __popcll(m_box), n_sph = __popcll(m_sph), n_oth = __popcll(m_oth), n_shd = __popcll(m_shd);
-            if (n_box >= n_sph && n_box >= n_oth && n_box >= n_shd) {
-                if (want == W_BOX) {
-                    step_box(L, cur, cnt);
-                    cur = prog[L.pc];
-                }
-            } else if (n_sph >= n_oth && n_sph >= n_shd) {
-                if (want == W_SPHERE) {
-                    step_sphere(L, cur, cnt);
-                    cur = prog[L.pc];
-                }
-            } else if (n_shd >= n_oth) {
-                if (want == W_SHADE) {
-                    if (shade<real, FEAT, COUNT>(L, prog, sc, cam, cnt)) {  // path ended: pixel_color += ray_color (Camera.txt:72)
-                        L.sum = L.sum + L.radiance;
-                        L.s += 1;
-                        if (L.s < cam.spp) {
-                            begin_sample(L, cam, i, j, seed_hash, cnt);
-                        } else {
-                            alive = false;
-                        }
-                    }
-                    if (alive) {
-                        begin_segment(L, cnt);
-                        cur = prog[0];
-                    }
-                }
-            } else {
-                if (want == W_OTHER) {
-                    step_other<real, FEAT, COUNT>(L, prog + L.pc, sc, cnt);
-                    cur = prog[L.pc];
-                }
-            }
+
+        // ---- vote
+        const Slot<real>* rec = prog + L.pc;
+        uint32_t kind = alive ? (rec->kind_payload & 15u) : uint32_t(OP_END);
+        const int want = !alive ? W_DONE : (kind == OP_BOX ? W_BOX : (kind == OP_SPHERE ? W_SPHERE : (kind == OP_END ? W_SHADE : W_OTHER)));
+        const unsigned long long m_box = __ballot(want == W_BOX);
+        const unsigned long long m_sph = __ballot(want == W_SPHERE);
+        const unsigned long long m_oth = __ballot(want == W_OTHER);
+        const unsigned long long m_shd = __ballot(want == W_SHADE);
+        if ((m_box | m_sph | m_oth | m_shd) == 0ull) {
+            if (exhausted) break;
+            continue;
         }
-        const V3<real> sum = scale(cam.samples_scale, L.sum);  // Camera.txt:74
-        if (tmap.compact) {
-            if (out_linear) {
-                real* base = out_linear + size_t(local_tile) * 192 + lane;
-                base[0] = sum.x;
-                base[64] = sum.y;
-                base[128] = sum.z;
+        const int n_box = int(__builtin_popcountll(m_box)), n_sph = int(__builtin_popcountll(m_sph));
+        const int n_oth = int(__builtin_popcountll(m_oth)), n_shd = int(__builtin_popcountll(m_shd));
+        if (n_box >= n_sph && n_box >= n_oth && n_box >= n_shd) {
+            // Box tests dominate (about 100 per sample against a dozen sphere tests), so
+            // the vote is amortised: keep stepping boxes -- one ballot and one branch per
+            // step -- until fewer than `keep` lanes are still sitting on a box record.
+            const int keep = n_box - (n_box >> 2) > 8 ? n_box - (n_box >> 2) : 8;  // ~3/4 of the lanes that started
+            bool on_box = want == W_BOX;
+            int remaining;
+            do {
+                if (on_box) {
+                    step_box(L, *rec, cnt);
+                    rec = prog + L.pc;
+                    on_box = (rec->kind_payload & 15u) == OP_BOX;
+                }
+                remaining = int(__builtin_popcountll(__ballot(on_box)));
+            } while (remaining >= keep);
+        } else if (n_sph >= n_oth && n_sph >= n_shd) {
+            if (want == W_SPHERE) {
+                if (diag & 32u) L.pc += 1;  // timing ablation only (tools/): skip the sphere maths
+                else step_sphere(L, *rec, cnt);
             }
-        } else if (active) {
-            const size_t idx = (size_t(j) * cam.width + i) * 3;
-            if (out_linear) {
-                out_linear[idx] = sum.x;
-                out_linear[idx + 1] = sum.y;
-                out_linear[idx + 2] = sum.z;
+        } else if (n_shd >= n_oth) {
+            if (want == W_SHADE) {
+                if (diag & 16u) L.best_pc = kNoHit;  // timing ablation only (tools/): every segment is treated as a miss
+                const bool ended = L.depth <= 0 || shade<real, FEAT, COUNT>(L, prog, sc, cam, cnt);
+                if (ended) {  // pixel_color += ray_color(...) (Camera.txt:72)
+                    L.sum = L.sum + L.radiance;
+                    L.s += 1;
+                    if (L.s < s_end) {
+                        begin_sample(L, cam, px_i, px_j, seed_hash, cnt);
+                    } else {
+                        alive = false;
+                        store_partial(partial, my_item, my_pix, L.sum);
+                    }
+                }
+                if (alive) {
+                    if (L.depth > 0) begin_segment(L, cnt);
+                    else L.pc = end_pc;
+                }
             }
-            if (out_rgb8) {
-                out_rgb8[idx] = to_byte(double(sum.x));
-                out_rgb8[idx + 1] = to_byte(double(sum.y));
-                out_rgb8[idx + 2] = to_byte(double(sum.z));
-            }
+        } else {
+            if (want == W_OTHER) step_other<real, FEAT, COUNT>(L, rec, sc, cnt);
         }
     }
     if constexpr (COUNT) {
@@ -823,6 +864,52 @@ __global__ __launch_bounds__(768) void rtk_render_kernel(SceneView<real> sc, Cam
             unsigned long long v = cnt.c[k];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
             if (lane == 0 && v) atomicAdd(&counters[k], v);
+        }
+    }
+}
+
+// Partial sums -> pixels.  For every pixel of this rank: add its chunks in index
+// order, scale by 1/spp (Camera.txt:74) and write either the row-major image
+// (+ gamma/clamp/quantised bytes, Camera.txt:77-89) or this rank's compact tile
+// buffer.  One thread per (local tile, pixel).
+template <typename real>
+__global__ __launch_bounds__(256) void rtk_resolve_kernel(const real* __restrict__ partial, TileMap tmap, int width, int height, real samples_scale,
+                                                           real* __restrict__ out_linear, uint8_t* __restrict__ out_rgb8) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int pix = int(gid & 63);
+    const long long local_tile = gid >> 6;
+    if (local_tile >= tmap.n_tiles_local) return;
+    const long long tile = local_tile * tmap.n_ranks + tmap.rank;
+    const int i = int(tile % tmap.tiles_x) * 8 + (pix & 7), j = int(tile / tmap.tiles_x) * 8 + (pix >> 3);
+    const bool inside = tile < (long long)tmap.tiles_x * tmap.tiles_y && i < width && j < height;
+    V3<real> sum = mk(real(0), real(0), real(0));
+    if (inside) {
+        const real* src = partial + size_t(local_tile) * tmap.n_chunks * 192 + pix;
+        sum = mk(src[0], src[64], src[128]);
+        for (int c = 1; c < tmap.n_chunks; c++) {
+            const real* q = src + size_t(c) * 192;
+            sum = sum + mk(q[0], q[64], q[128]);
+        }
+        sum = scale(samples_scale, sum);
+    }
+    if (tmap.compact) {
+        if (out_linear) {
+            real* base = out_linear + size_t(local_tile) * 192 + pix;
+            base[0] = sum.x;
+            base[64] = sum.y;
+            base[128] = sum.z;
+        }
+    } else if (inside) {
+        const size_t idx = (size_t(j) * width + i) * 3;
+        if (out_linear) {
+            out_linear[idx] = sum.x;
+            out_linear[idx + 1] = sum.y;
+            out_linear[idx + 2] = sum.z;
+        }
+        if (out_rgb8) {
+            out_rgb8[idx] = to_byte(double(sum.x));
+            out_rgb8[idx + 1] = to_byte(double(sum.y));
+            out_rgb8[idx + 2] = to_byte(double(sum.z));
         }
     }
 }
@@ -892,17 +979,18 @@ static hipError_t plan_launch(Kernel kernel, size_t lds_bytes, int n_tiles, int&
 }
 
 template <typename real, uint32_t FEAT, bool COUNT, bool IN_LDS>
-static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>& cam, const TileMap& tmap, uint32_t seed, void* out_linear, uint8_t* out_rgb8,
-                             unsigned long long* counters, unsigned int* tile_counter, hipStream_t stream) {
-    if (tmap.n_tiles_local <= 0) return hipSuccess;
+static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>* cam, const TileMap& tmap, uint32_t seed, void* partial,
+                             unsigned long long* counters, unsigned int* tile_counter, uint32_t diag, hipStream_t stream) {
+    const int n_items = tmap.n_tiles_local * tmap.n_chunks;
+    if (n_items <= 0) return hipSuccess;
     auto kernel = rtk_render_kernel<real, FEAT, COUNT, IN_LDS>;
     const size_t lds = IN_LDS ? size_t(sc.n_slots) * sizeof(Slot<real>) : 0;
     int blocks = 0, threads = 0;
-    hipError_t e = plan_launch(kernel, lds, tmap.n_tiles_local, blocks, threads);
+    hipError_t e = plan_launch(kernel, lds, n_items, blocks, threads);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(tile_counter, 0, sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
-    kernel<<<dim3(blocks), dim3(threads), lds, stream>>>(sc, cam, tmap, seed, static_cast<real*>(out_linear), out_rgb8, counters, tile_counter);
+    kernel<<<dim3(blocks), dim3(threads), lds, stream>>>(sc, cam, tmap, seed, static_cast<real*>(partial), counters, tile_counter, diag);
     return hipGetLastError();
 }
 
@@ -912,22 +1000,34 @@ bool program_fits_lds(const SceneView<real>& sc) {
 }
 
 template <typename real>
-hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>& cam, const TileMap& tmap, uint32_t seed, uint32_t features, bool count,
-                         bool allow_lds, void* out_linear, uint8_t* out_rgb8, unsigned long long* counters, unsigned int* tile_counter, hipStream_t stream) {
+hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>* cam, const TileMap& tmap, uint32_t seed, uint32_t features, bool count,
+                         bool allow_lds, uint32_t diag, void* partial, unsigned long long* counters, unsigned int* tile_counter, hipStream_t stream) {
     const bool lds = allow_lds && program_fits_lds(sc);
-    if (count) return launch_one<real, kFeatAll, true, false>(sc, cam, tmap, seed, out_linear, out_rgb8, counters, tile_counter, stream);
+    if (count) return launch_one<real, kFeatAll, true, false>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream);
     if (features == kFeatLean)
-        return lds ? launch_one<real, kFeatLean, false, true>(sc, cam, tmap, seed, out_linear, out_rgb8, counters, tile_counter, stream)
-                   : launch_one<real, kFeatLean, false, false>(sc, cam, tmap, seed, out_linear, out_rgb8, counters, tile_counter, stream);
-    return lds ? launch_one<real, kFeatAll, false, true>(sc, cam, tmap, seed, out_linear, out_rgb8, counters, tile_counter, stream)
-               : launch_one<real, kFeatAll, false, false>(sc, cam, tmap, seed, out_linear, out_rgb8, counters, tile_counter, stream);
+        return lds ? launch_one<real, kFeatLean, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream)
+                   : launch_one<real, kFeatLean, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream);
+    return lds ? launch_one<real, kFeatAll, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream)
+               : launch_one<real, kFeatAll, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream);
 }
-template hipError_t launch_render<double>(const SceneView<double>&, const CameraRec<double>&, const TileMap&, uint32_t, uint32_t, bool, bool, void*, uint8_t*,
+template hipError_t launch_render<double>(const SceneView<double>&, const CameraRec<double>*, const TileMap&, uint32_t, uint32_t, bool, bool, uint32_t, void*,
                                           unsigned long long*, unsigned int*, hipStream_t);
-template hipError_t launch_render<float>(const SceneView<float>&, const CameraRec<float>&, const TileMap&, uint32_t, uint32_t, bool, bool, void*, uint8_t*,
+template hipError_t launch_render<float>(const SceneView<float>&, const CameraRec<float>*, const TileMap&, uint32_t, uint32_t, bool, bool, uint32_t, void*,
                                          unsigned long long*, unsigned int*, hipStream_t);
 template bool program_fits_lds<double>(const SceneView<double>&);
 template bool program_fits_lds<float>(const SceneView<float>&);
+
+template <typename real>
+hipError_t launch_resolve(const void* partial, const TileMap& tmap, int width, int height, double samples_scale, void* out_linear, uint8_t* out_rgb8,
+                          hipStream_t stream) {
+    const long long slots = (long long)tmap.n_tiles_local * 64;
+    if (slots <= 0) return hipSuccess;
+    rtk_resolve_kernel<real><<<dim3(int((slots + 255) / 256)), dim3(256), 0, stream>>>(static_cast<const real*>(partial), tmap, width, height,
+                                                                                      real(samples_scale), static_cast<real*>(out_linear), out_rgb8);
+    return hipGetLastError();
+}
+template hipError_t launch_resolve<double>(const void*, const TileMap&, int, int, double, void*, uint8_t*, hipStream_t);
+template hipError_t launch_resolve<float>(const void*, const TileMap&, int, int, double, void*, uint8_t*, hipStream_t);
 
 template <typename real>
 hipError_t launch_unpermute(const void* gathered, int width, int height, int n_ranks, long long tiles_per_rank, void* out_linear, uint8_t* out_rgb8,

@@ -1,0 +1,15 @@
+"""Scene/size table shared by the golden generator and the tests."""
+SCENE_SEED = 0x5EED2025
+RENDER_SEED = 1
+
+# (scene, width, height, spp, max_depth): small enough for the CPU oracle in seconds.
+IMAGE_CASES = [
+    ("three_spheres", 64, 36, 8, 10),
+    ("book1_final", 64, 36, 4, 50),
+    ("cornell_box", 40, 40, 8, 25),
+    ("mesh", 64, 36, 4, 10),
+    ("book2_final", 64, 36, 4, 10),
+    ("material_zoo", 96, 54, 8, 12),
+    ("cornell_smoke", 48, 48, 8, 10),
+    ("single_fog", 48, 32, 16, 8),
+]

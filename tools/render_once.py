@@ -1,0 +1,34 @@
+"""Profiling target: upload a config scene and launch the render kernel a fixed number of times.
+
+  python3 tools/render_once.py [config=c2] [real=f64|f32] [launches=2] [spp=0] [variant=0]
+Used under rocprofv3 (--kernel-trace --stats, or --pmc passes); prints the event-timed kernel ms.
+"""
+import os, sys, tempfile
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import raytracingoneweekendapplication_amd as rt
+
+config = sys.argv[1] if len(sys.argv) > 1 else "c2"
+real = rt.RTK_REAL_F64 if (len(sys.argv) <= 2 or sys.argv[2] == "f64") else rt.RTK_REAL_F32
+launches = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+spp = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+variant = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+tmp = tempfile.mkdtemp()
+earth = rt.write_synthetic_earth(os.path.join(tmp, "earth_synth.ppm"))
+scene = rt.Scene.build(rt.CONFIG_SCENES[config], rt.SCENE_SEED, earth)
+cam = scene.camera(0, 0, spp, 0)
+r = rt.Renderer(0)
+r.upload(scene)
+dev = torch.device("cuda", 0)
+H, W = cam.image_height, cam.image_width
+img = torch.empty((H, W, 3), dtype=torch.float64 if real == rt.RTK_REAL_F64 else torch.float32, device=dev)
+u8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+stream = torch.cuda.current_stream().cuda_stream
+for k in range(launches):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r.render_device(cam, img.data_ptr(), u8.data_ptr(), real_mode=real, variant=variant, stream=stream)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1)
+    print(f"launch {k}: {ms:.3f} ms  {W*H*cam.samples_per_pixel/ms/1e3:.1f} Msamples/s  kernel={r.kernel_name(real, variant)}", flush=True)

@@ -59,11 +59,23 @@ def parse_args():
     return p.parse_args()
 
 
+def host_cores():
+    """CPU cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(rt, scene_name, cam, earth, target_seconds):
     """Time the CPU path on this host: reference classes if the prebuilt driver is here, else the port."""
     from oracle import orc
 
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     W, H, depth = cam.image_width, cam.image_height, cam.max_depth
     if os.path.exists(orc.REF_DRIVER):
         def run(spp):
@@ -221,7 +233,7 @@ def main():
         try:
             cpu = cpu_baseline(rt, scene_name, cam, earth, args.cpu_seconds)
         except Exception as exc:  # the baseline is reported, never required
-            cpu = {"value": None, "unit": "Msamples/s", "cores": os.cpu_count(), "kind": "unavailable", "sample": f"failed: {exc}"}
+            cpu = {"value": None, "unit": "Msamples/s", "cores": host_cores(), "kind": "unavailable", "sample": f"failed: {exc}"}
 
     if rank == 0:
         line = {

@@ -137,3 +137,19 @@ def test_synthetic_earth_texture_is_deterministic(rt):
         a = open(rt.write_synthetic_earth(os.path.join(tmp, "a.ppm"), 64, 32), "rb").read()
         b = open(rt.write_synthetic_earth(os.path.join(tmp, "b.ppm"), 64, 32), "rb").read()
     assert a == b and a.startswith(b"P6\n64 32\n255\n") and len(a) == 13 + 64 * 32 * 3
+
+
+def test_reference_style_program_compiles_and_links_against_the_drop_in_headers(rt, tmp_path):
+    """Scene code in the reference's style (examples/) builds against host/ + include/ and links librtk_hip.so;
+    without a GPU, camera::render reports the missing device instead of rendering on the host."""
+    exe = tmp_path / "scene"
+    pkg = os.path.dirname(rt.HIP_LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "examples", "reference_style_scene.cpp"),
+                           "-I" + os.path.join(pkg, "host"), "-I" + os.path.join(ROOT, "include"), "-L" + pkg, "-lrtk_hip",
+                           "-Wl,-rpath," + pkg, "-o", str(exe)])
+    import torch
+
+    if not torch.cuda.is_available():
+        out = subprocess.run([str(exe), "32", "1"], capture_output=True, text=True, cwd=tmp_path, timeout=120)
+        assert "camera::render failed" in out.stderr and "no HIP device" in out.stderr
+        assert not (tmp_path / "reference_style_scene.png").exists()

@@ -18,7 +18,7 @@ from typing import Optional
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_PKG_DIR)
-HIP_LIB_PATH = os.path.join(_PKG_DIR, "librtk_hip.so")
+HIP_LIB_PATH = os.environ.get("RTK_HIP_LIB") or os.path.join(_PKG_DIR, "librtk_hip.so")  # the override is for tools/ (diagnostic builds)
 HOST_LIB_PATH = os.path.join(_PKG_DIR, "librtk_host.so")
 
 RTK_ABI_VERSION = 1

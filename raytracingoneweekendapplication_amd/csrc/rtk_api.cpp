@@ -79,6 +79,7 @@ struct Compiler {
         auto it = prog.chain_ids.find(c);
         if (it != prog.chain_ids.end()) return it->second;
         uint32_t id = uint32_t(prog.chains.size());
+        if (id > 255u) bad(RTK_ERR_UNSUPPORTED, "more than 255 distinct instance-transform chains");  // 8 bits of a record's aux word
         prog.chains.push_back(c);
         prog.chain_ids[c] = id;
         return id;
@@ -182,6 +183,7 @@ bool texture_needs_uv(const rtk_scene_desc& sc, int32_t tex, int depth = 0) {
 int validate_tables(const rtk_scene_desc& sc) {
     if (sc.abi_version != RTK_ABI_VERSION) return fail(RTK_ERR_INVALID, "scene abi_version %d != %d", sc.abi_version, RTK_ABI_VERSION);
     if (sc.n_nodes <= 0 || !sc.nodes) return fail(RTK_ERR_INVALID, "scene has no nodes (the reference recurses forever on an empty world, bvh.h:38-43)");
+    if (sc.n_materials >= (1 << 24)) return fail(RTK_ERR_UNSUPPORTED, "more than 2^24 materials");
     for (int32_t i = 0; i < sc.n_textures; i++) {
         const rtk_texture& t = sc.textures[i];
         switch (t.kind) {
@@ -285,6 +287,7 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
         Slot<real>* rec = &slots[slot_of_op[i]];
         rec->kind_payload = make_op(kind, payload);
         rec->aux = op.aux;
+        auto with_material = [&](int32_t material) { rec->aux = (op.aux & 255u) | (uint32_t(material) << 8); };
         switch (kind) {
             case OP_BOX: {
                 const rtk_aabb& b = sc.bvh_boxes[payload];
@@ -298,6 +301,7 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
                 const rtk_sphere& s = sc.spheres[payload];
                 const double vals[4] = {s.center0.x, s.center0.y, s.center0.z, s.radius};
                 pack(rec, vals, 4);
+                with_material(s.material);
                 if (kind == OP_SPHERE_MOVING) {
                     const double dir[3] = {s.center_dir.x, s.center_dir.y, s.center_dir.z};
                     pack(rec + 1, dir, 3);
@@ -309,6 +313,7 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
                 const double vals[16] = {q.normal.x, q.normal.y, q.normal.z, q.D, q.Q.x, q.Q.y, q.Q.z, q.w.x, q.w.y, q.w.z,
                                          q.v.x, q.v.y, q.v.z, q.u.x, q.u.y, q.u.z};
                 pack(rec, vals, 16);
+                with_material(q.material);
                 break;
             }
             case OP_TRI: {
@@ -317,10 +322,14 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
                 const double vals[9] = {t.p2.x - t.p0.x, t.p2.y - t.p0.y, t.p2.z - t.p0.z, t.p1.x - t.p0.x, t.p1.y - t.p0.y, t.p1.z - t.p0.z,
                                         t.p0.x, t.p0.y, t.p0.z};
                 pack(rec, vals, 9);
+                with_material(t.material);
                 break;
             }
             case OP_MED_MID: rec->aux = slot_of_op[op.aux]; break;
-            case OP_MED_END: rec->v[0] = real(sc.media[payload].neg_inv_density); break;
+            case OP_MED_END:
+                rec->v[0] = real(sc.media[payload].neg_inv_density);
+                with_material(sc.media[payload].material);
+                break;
             default: break;
         }
     }
@@ -436,6 +445,7 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
     if ((rc = out.upload(lights, &out.view.lights)) != RTK_OK) return rc;
     out.view.n_slots = int32_t(slots.size());
     out.view.n_lights = sc.n_lights;
+    out.view.n_materials = sc.n_materials;
     return RTK_OK;
 }
 

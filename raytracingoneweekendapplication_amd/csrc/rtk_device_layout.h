@@ -34,13 +34,14 @@ namespace rtk {
 enum OpKind : uint32_t {
     OP_END = 0,
     OP_BOX = 1,        // 1 slot : v = xmin,xmax,ymin,ymax,zmin,zmax; aux = pc to continue at when the slab test fails
-    OP_SPHERE = 2,     // 1 slot : v = cx,cy,cz,radius (static sphere); payload = sphere index, aux = chain id
-    OP_QUAD = 3,       // 3 slots: n(3),D,Q(3),w(3),v(3),u(3) packed over the slots' v[]; payload = quad index, aux = chain id
-    OP_TRI = 4,        // 2 slots: e2(3),e1(3),p0(3); payload = triangle index, aux = chain id
+    // primitive records: aux = chain id (bits 0..7) | material index (bits 8..31)
+    OP_SPHERE = 2,     // 1 slot : v = cx,cy,cz,radius (static sphere); payload = sphere index
+    OP_QUAD = 3,       // 3 slots: n(3),D,Q(3),w(3),v(3),u(3) packed over the slots' v[]; payload = quad index
+    OP_TRI = 4,        // 2 slots: e2(3),e1(3),p0(3); payload = triangle index
     OP_CHAIN = 5,      // 1 slot : payload = chain id to make current, aux = number of transform entries it stands for
     OP_MED_BEGIN = 6,  // 1 slot : payload = medium index
     OP_MED_MID = 7,    // 1 slot : payload = medium index, aux = pc after the matching OP_MED_END
-    OP_MED_END = 8,    // 1 slot : v[0] = neg_inv_density; payload = medium index, aux = chain id
+    OP_MED_END = 8,    // 1 slot : v[0] = neg_inv_density; payload = medium index, aux = chain | material << 8
     OP_SPHERE_MOVING = 9  // 2 slots: as OP_SPHERE, then v = dx,dy,dz (center2 - center1)
 };
 
@@ -165,7 +166,7 @@ struct SceneView {  // device pointers, passed to the kernel by value
     const PerlinRec<real>* perlins;
     const ChainRec<real>* chains;
     const LightRec<real>* lights;
-    int32_t n_slots, n_lights;
+    int32_t n_slots, n_lights, n_materials;
 };
 
 struct TileMap {  // which tiles this launch renders and where the pixels go

@@ -22,6 +22,9 @@
 // are pure functions of (ray, t, primitive).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "rtk.h"
 #include "rtk_device_layout.h"
 #include "rtk_trace.h"
@@ -73,6 +76,15 @@ RTK_DEV double rt_atan2(double y, double x) { return atan2(y, x); }
 RTK_DEV float rt_atan2(float y, float x) { return atan2f(y, x); }
 
 template <typename real> RTK_DEV real real_inf() { return real(__builtin_huge_val()); }
+
+// v_min/v_max as single instructions.  __builtin_fmin/fmax are IEEE minnum/maxnum, for which the
+// compiler first canonicalises every operand it cannot prove quiet (an extra v_max x,x per use).
+// Operands here are results of arithmetic or interval ends, never signalling NaNs; a quiet NaN
+// operand is dropped exactly as minnum/maxnum drop it.
+RTK_DEV double raw_min(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RTK_DEV double raw_max(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RTK_DEV float raw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RTK_DEV float raw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 template <typename real> RTK_DEV V3<real> unit_vector(V3<real> a) { return divide(a, rt_sqrt(length_squared(a))); }
 template <typename real> RTK_DEV bool near_zero(V3<real> a) {
     const real s = real(1e-8);
@@ -167,32 +179,34 @@ RTK_DEV void unapply_chain(const ChainRec<real>* __restrict__ chains, uint32_t c
 
 // ------------------------------------------------------------------ traversal --
 // aabb::hit (aabb.h:61-85).  The reference's per-axis early-outs reduce to one
-// final comparison because tmin only grows and tmax only shrinks; NaNs from
-// 0*inf are handled exactly as its `<`/`>` comparisons handle them (the select
-// keeps the reference's else-branch, fmax/fmin drop a NaN operand).
-template <typename real>
+// final comparison because tmin only grows and tmax only shrinks.
+//
+// EXACT_NAN = true is the literal form: per axis `t0 < t1` selects near/far (a NaN
+// from 0*inf makes the comparison false, i.e. the reference's else-branch), and
+// max/min then drop a NaN operand exactly as its `>`/`<` updates do.
+// EXACT_NAN = false is for rays whose 1/d is finite and non-zero on every axis
+// (Lane::regular): then t0 and t1 cannot be NaN (bounds and origin are finite), and
+// near = min(t0,t1), far = max(t0,t1) are the same values as the select -- five
+// instructions fewer per axis.  Rays with a zero or infinite direction component
+// take the exact form (the aabb known-answer vectors exercise them).
+template <bool EXACT_NAN, typename real>
 RTK_DEV bool slab_test(const Slot<real>& b, V3<real> o, V3<real> inv, real tmin, real tmax) {
-    {
-        real t0 = (b.v[0] - o.x) * inv.x, t1 = (b.v[1] - o.x) * inv.x;
-        bool lt = t0 < t1;
-        real nr = lt ? t0 : t1, fr = lt ? t1 : t0;
-        tmin = rt_fmax(nr, tmin);
-        tmax = rt_fmin(fr, tmax);
+    const real t0x = (b.v[0] - o.x) * inv.x, t1x = (b.v[1] - o.x) * inv.x;
+    const real t0y = (b.v[2] - o.y) * inv.y, t1y = (b.v[3] - o.y) * inv.y;
+    const real t0z = (b.v[4] - o.z) * inv.z, t1z = (b.v[5] - o.z) * inv.z;
+    real nx, fx, ny, fy, nz, fz;
+    if constexpr (EXACT_NAN) {
+        const bool lx = t0x < t1x, ly = t0y < t1y, lz = t0z < t1z;
+        nx = lx ? t0x : t1x; fx = lx ? t1x : t0x;
+        ny = ly ? t0y : t1y; fy = ly ? t1y : t0y;
+        nz = lz ? t0z : t1z; fz = lz ? t1z : t0z;
+    } else {
+        nx = raw_min(t0x, t1x); fx = raw_max(t0x, t1x);
+        ny = raw_min(t0y, t1y); fy = raw_max(t0y, t1y);
+        nz = raw_min(t0z, t1z); fz = raw_max(t0z, t1z);
     }
-    {
-        real t0 = (b.v[2] - o.y) * inv.y, t1 = (b.v[3] - o.y) * inv.y;
-        bool lt = t0 < t1;
-        real nr = lt ? t0 : t1, fr = lt ? t1 : t0;
-        tmin = rt_fmax(nr, tmin);
-        tmax = rt_fmin(fr, tmax);
-    }
-    {
-        real t0 = (b.v[4] - o.z) * inv.z, t1 = (b.v[5] - o.z) * inv.z;
-        bool lt = t0 < t1;
-        real nr = lt ? t0 : t1, fr = lt ? t1 : t0;
-        tmin = rt_fmax(nr, tmin);
-        tmax = rt_fmin(fr, tmax);
-    }
+    tmin = raw_max(nz, raw_max(ny, raw_max(nx, tmin)));
+    tmax = raw_min(fz, raw_min(fy, raw_min(fx, tmax)));
     return tmax > tmin;
 }
 
@@ -283,9 +297,17 @@ struct Lane {
     real sv_tmin, sv_best_t, rec1_t;  // constant_medium::hit nests two closest-hit queries of its boundary
                                       // (constant_medium.h:23,26); the outer query is parked here meanwhile
     V3<real> throughput, radiance, sum;
-    uint32_t pc, best_pc, sv_best_pc, rng;
+    uint32_t pc, kind, best_pc, sv_best_pc, rng;  // kind = record kind at pc (kept in a register so the vote needs no LDS read)
     int depth, s;
+    bool regular;            // 1/d finite and non-zero on all three axes: slab tests cannot produce NaNs
 };
+
+template <typename real>
+RTK_DEV bool regular_direction(V3<real> inv) {
+    const real inf = real_inf<real>();
+    return rt_fabs(inv.x) > real(0) && rt_fabs(inv.x) < inf && rt_fabs(inv.y) > real(0) && rt_fabs(inv.y) < inf && rt_fabs(inv.z) > real(0) &&
+           rt_fabs(inv.z) < inf;
+}
 
 // world.hit(r, interval(0.001, inf), rec) (Camera.txt:211) starts here.
 template <typename real, bool COUNT>
@@ -295,6 +317,7 @@ RTK_DEV void begin_segment(Lane<real>& L, Counters<COUNT>& cnt) {
     L.d = L.rd;
     L.inv = mk(real(1) / L.d.x, real(1) / L.d.y, real(1) / L.d.z);
     L.a = length_squared(L.d);
+    L.regular = regular_direction(L.inv);
     L.tmin = real(0.001);
     L.best_t = real_inf<real>();
     L.best_pc = kNoHit;
@@ -302,10 +325,10 @@ RTK_DEV void begin_segment(Lane<real>& L, Counters<COUNT>& cnt) {
 }
 
 // bvh_node::hit's box test (bvh.h:65): on a miss skip the whole subtree.
-template <typename real, bool COUNT>
+template <bool EXACT_NAN, typename real, bool COUNT>
 RTK_DEV void step_box(Lane<real>& L, const Slot<real>& rec, Counters<COUNT>& cnt) {
     cnt.inc(C_BOX);
-    const bool hit = slab_test(rec, L.o, L.inv, L.tmin, L.best_t);
+    const bool hit = slab_test<EXACT_NAN>(rec, L.o, L.inv, L.tmin, L.best_t);
     L.pc = hit ? L.pc + 1 : rec.aux;
 }
 
@@ -358,6 +381,7 @@ RTK_DEV void step_other(Lane<real>& L, const Slot<real>* __restrict__ rec, const
         apply_chain(sc.chains, kp >> 4, L.ro, L.rd, L.o, L.d);
         L.inv = mk(real(1) / L.d.x, real(1) / L.d.y, real(1) / L.d.z);
         L.a = length_squared(L.d);
+        L.regular = regular_direction(L.inv);
         L.pc += 1;
     } else if ((FEAT & F_MEDIA) && kind == OP_MED_BEGIN) {
         cnt.inc(C_MEDIUM);
@@ -499,14 +523,17 @@ struct Surface {  // hit_record (hittable.h:11-27)
     bool front_face;
 };
 
-// Build the hit record of the winning op (the deferred half of *.hit).
+// Build the hit record of the winning record (the deferred half of *.hit).  Sphere
+// and quad geometry is read from the program slot itself (LDS when staged); only
+// triangles go to their side record for the normal and the UVs.
 template <typename real, uint32_t FEAT>
-RTK_DEV void make_surface(const Slot<real>* __restrict__ prog, const SceneView<real>& sc, uint32_t best_pc, real t, V3<real> wo, V3<real> wd, real tm,
-                          Surface<real>& sf) {
+RTK_DEV void make_surface(const Slot<real>* __restrict__ prog, const SceneView<real>& sc, const MaterialRec<real>* __restrict__ mats, uint32_t best_pc, real t,
+                          V3<real> wo, V3<real> wd, real tm, Surface<real>& sf) {
     const Slot<real>* rec = prog + best_pc;
     const uint32_t kind = rec->kind_payload & 15u;
     const uint32_t idx = rec->kind_payload >> 4;
-    const uint32_t chain = (FEAT & F_XFORM) ? rec->aux : 0u;
+    const uint32_t chain = (FEAT & F_XFORM) ? (rec->aux & 255u) : 0u;
+    sf.material = int(rec->aux >> 8);
     V3<real> o = wo, d = wd;
     if (FEAT & F_XFORM) apply_chain(sc.chains, chain, wo, wd, o, d);
     sf.p = o + scale(t, d);
@@ -515,24 +542,22 @@ RTK_DEV void make_surface(const Slot<real>* __restrict__ prog, const SceneView<r
     V3<real> outward;
     bool face_from_ray = true;
     if (kind == OP_SPHERE || kind == OP_SPHERE_MOVING) {  // sphere.h:50-56,67-73
-        const SphereRec<real>& s = sc.spheres[idx];
-        V3<real> cc = mk(s.cx, s.cy, s.cz) + scale(tm, mk(s.dx, s.dy, s.dz));
-        outward = divide(sf.p - cc, s.radius);
-        sf.material = s.material;
-        if ((FEAT & F_TEXTURE) && sc.materials[s.material].needs_uv) {
+        V3<real> cc = mk(rec->v[0], rec->v[1], rec->v[2]);
+        if (kind == OP_SPHERE_MOVING) cc = cc + scale(tm, mk(rec[1].v[0], rec[1].v[1], rec[1].v[2]));
+        outward = divide(sf.p - cc, rec->v[3]);
+        if ((FEAT & F_TEXTURE) && mats[sf.material].needs_uv) {
             const real pi = real(3.1415926535897932385);
             real theta = rt_acos(-outward.y);
             real phi = rt_atan2(-outward.z, outward.x) + pi;
             sf.u = phi / (real(2) * pi);
             sf.v = theta / pi;
         }
-    } else if ((FEAT & F_QUAD) && kind == OP_QUAD) {  // quad.h:44-57
-        const QuadRec<real>& q = sc.quads[idx];
-        V3<real> planar = sf.p - ld3(q.Q);
-        sf.u = dot(ld3(q.w), cross(planar, ld3(q.v)));
-        sf.v = dot(ld3(q.w), cross(ld3(q.u), planar));
-        outward = ld3(q.n);
-        sf.material = q.material;
+    } else if ((FEAT & F_QUAD) && kind == OP_QUAD) {  // quad.h:44-57; record = n(3),D,Q(3),w(3),v(3),u(3)
+        V3<real> planar = sf.p - packed3<real, 4>(rec);
+        V3<real> w = packed3<real, 7>(rec);
+        sf.u = dot(w, cross(planar, packed3<real, 10>(rec)));
+        sf.v = dot(w, cross(packed3<real, 13>(rec), planar));
+        outward = packed3<real, 0>(rec);
     } else if ((FEAT & F_TRI) && kind == OP_TRI) {  // triangle.h:96-110
         const TriRec<real>& tr = sc.tris[idx];
         real tt;
@@ -541,10 +566,8 @@ RTK_DEV void make_surface(const Slot<real>* __restrict__ prog, const SceneView<r
         sf.u = real(fa * tr.uv0[0] + fb * tr.uv1[0] + fg * tr.uv2[0]);
         sf.v = real(fa * tr.uv0[1] + fb * tr.uv1[1] + fg * tr.uv2[1]);
         outward = ld3(tr.n);
-        sf.material = tr.material;
     } else {  // OP_MED_END: constant_medium.h:45-50
         outward = mk(real(1), real(0), real(0));
-        sf.material = sc.media[idx].material;
         face_from_ray = false;
     }
     if (face_from_ray) {  // hittable.h:23-26
@@ -610,15 +633,16 @@ RTK_DEV void begin_sample(Lane<real>& L, const CameraRec<real>& cam, int i, int 
 // (Camera.txt:211-237), iteratively (radiance = sum of throughput * emission).
 // Returns true when the sample's path has ended.
 template <typename real, uint32_t FEAT, bool COUNT>
-RTK_DEV bool shade(Lane<real>& L, const Slot<real>* __restrict__ prog, const SceneView<real>& sc, const CameraRec<real>& cam, Counters<COUNT>& cnt) {
+RTK_DEV bool shade(Lane<real>& L, const Slot<real>* __restrict__ prog, const SceneView<real>& sc, const MaterialRec<real>* __restrict__ mats,
+                   const CameraRec<real>& cam, Counters<COUNT>& cnt) {
     if (L.best_pc == kNoHit) {  // Camera.txt:211-213
         L.radiance = L.radiance + L.throughput * ld3(cam.background);
         return true;
     }
     cnt.inc(C_SURFACE);
     Surface<real> sf;
-    make_surface<real, FEAT>(prog, sc, L.best_pc, L.best_t, L.ro, L.rd, L.tm, sf);
-    const MaterialRec<real>& m = sc.materials[sf.material];
+    make_surface<real, FEAT>(prog, sc, mats, L.best_pc, L.best_t, L.ro, L.rd, L.tm, sf);
+    const MaterialRec<real>& m = mats[sf.material];
     const V3<real> rd = L.rd;
 
     V3<real> attenuation, next_d;
@@ -709,6 +733,33 @@ RTK_DEV uint8_t to_byte(double x) {  // Camera.txt:29-34,77-83
 // bit-identical to a lock-step execution.
 enum Want : int { W_DONE = 0, W_BOX = 1, W_SPHERE = 2, W_OTHER = 3, W_SHADE = 4 };
 
+// Diagnostic build only (tools/profile_phases.py compiles this file with -DRTK_PROFILE into a separate
+// library): s_memtime stamps at the scheduler's phase boundaries; per phase the wave adds its cycles,
+// step count and active-lane count to counters[3*phase .. 3*phase+2].  The product build has none of it.
+#ifdef RTK_PROFILE
+#define RTK_PROF_DECL unsigned long long prof_t[6] = {0, 0, 0, 0, 0, 0}, prof_n[6] = {0, 0, 0, 0, 0, 0}, prof_l[6] = {0, 0, 0, 0, 0, 0}; \
+    unsigned long long prof_prev = __builtin_amdgcn_s_memtime();
+#define RTK_PROF_MARK(phase, steps, lanes)                           \
+    {                                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        prof_t[phase] += now_ - prof_prev;                           \
+        prof_n[phase] += (steps);                                    \
+        prof_l[phase] += (lanes);                                    \
+        prof_prev = now_;                                            \
+    }
+#define RTK_PROF_FLUSH                                                        \
+    if (lane == 0)                                                            \
+        for (int ph_ = 0; ph_ < 6; ph_++) {                                   \
+            atomicAdd(&counters[3 * ph_], prof_t[ph_]);                       \
+            atomicAdd(&counters[3 * ph_ + 1], prof_n[ph_]);                   \
+            atomicAdd(&counters[3 * ph_ + 2], prof_l[ph_]);                   \
+        }
+#else
+#define RTK_PROF_DECL
+#define RTK_PROF_MARK(phase, steps, lanes)
+#define RTK_PROF_FLUSH
+#endif
+
 // A finished (pixel, chunk): its sum of ray_color values goes to partial[item][3][64].
 template <typename real>
 RTK_DEV void store_partial(real* __restrict__ partial, int item, int pix, V3<real> sum) {
@@ -718,19 +769,30 @@ RTK_DEV void store_partial(real* __restrict__ partial, int item, int pix, V3<rea
     base[128] = sum.z;
 }
 
+// Workgroup-size bound: 768 threads = 3 waves per SIMD = up to 168 VGPRs.  The full-feature f64 kernel
+// needs more registers than that (it spilled ~560 B/lane at 168), so it is bounded at 512 threads
+// (2 waves per SIMD, 256 VGPRs).
+template <typename real, uint32_t FEAT>
+constexpr int max_threads() { return (sizeof(real) == 8 && FEAT != kFeatLean) ? 512 : 768; }
+
 template <typename real, uint32_t FEAT, bool COUNT, bool IN_LDS>
-__global__ __launch_bounds__(768) void rtk_render_kernel(SceneView<real> sc, const CameraRec<real>* __restrict__ cam_ptr, TileMap tmap, uint32_t seed,
+__global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel(SceneView<real> sc, const CameraRec<real>* __restrict__ cam_ptr, TileMap tmap, uint32_t seed,
                                                           real* __restrict__ partial, unsigned long long* __restrict__ counters,
                                                           unsigned int* __restrict__ tile_counter, uint32_t diag) {
     extern __shared__ __align__(16) unsigned char lds_program[];
     const Slot<real>* prog = sc.program;
-    if constexpr (IN_LDS) {
+    const MaterialRec<real>* mats = sc.materials;
+    if constexpr (IN_LDS) {  // program, then the material table, both as 16-byte words
+        const int n_prog16 = sc.n_slots * int(sizeof(Slot<real>) / 16);
+        const int n_mat16 = sc.n_materials * int(sizeof(MaterialRec<real>) / 16);
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(sc.program);
+        const uint4* __restrict__ msrc = reinterpret_cast<const uint4*>(sc.materials);
         uint4* dst = reinterpret_cast<uint4*>(lds_program);
-        const int n16 = sc.n_slots * int(sizeof(Slot<real>) / 16);
-        for (int k = threadIdx.x; k < n16; k += blockDim.x) dst[k] = src[k];
+        for (int k = threadIdx.x; k < n_prog16; k += blockDim.x) dst[k] = src[k];
+        for (int k = threadIdx.x; k < n_mat16; k += blockDim.x) dst[n_prog16 + k] = msrc[k];
         __syncthreads();
         prog = reinterpret_cast<const Slot<real>*>(lds_program);
+        mats = reinterpret_cast<const MaterialRec<real>*>(lds_program + size_t(n_prog16) * 16);
     }
     // The camera lives in device memory and is read with scalar loads where it is
     // used (once per sample); as a by-value argument it would sit in registers for
@@ -752,8 +814,10 @@ __global__ __launch_bounds__(768) void rtk_render_kernel(SceneView<real> sc, con
 
     Lane<real> L;
     L.pc = end_pc;
+    L.kind = OP_END;
     L.sum = mk(real(0), real(0), real(0));
     L.s = 0;
+    RTK_PROF_DECL
     bool alive = false;               // this lane currently owns a (pixel, chunk)
     int my_item = 0, my_pix = 0, px_i = 0, px_j = 0, s_end = 0;
 
@@ -793,6 +857,7 @@ __global__ __launch_bounds__(768) void rtk_render_kernel(SceneView<real> sc, con
                     begin_sample(L, cam, px_i, px_j, seed_hash, cnt);
                     if (L.depth > 0) begin_segment(L, cnt);
                     else L.pc = end_pc;  // max_depth == 0: ray_color returns black at once (Camera.txt:205-206)
+                    L.kind = prog[L.pc].kind_payload & 15u;
                 }
             }
             const int n_idle = int(__builtin_popcountll(m_idle));
@@ -801,9 +866,8 @@ __global__ __launch_bounds__(768) void rtk_render_kernel(SceneView<real> sc, con
             if (n_idle <= avail) break;  // every idle lane was offered a pixel this round (some fell outside the image)
         }
 
-        // ---- vote
-        const Slot<real>* rec = prog + L.pc;
-        uint32_t kind = alive ? (rec->kind_payload & 15u) : uint32_t(OP_END);
+        // ---- vote (registers and scalar unit only)
+        const uint32_t kind = L.kind;
         const int want = !alive ? W_DONE : (kind == OP_BOX ? W_BOX : (kind == OP_SPHERE ? W_SPHERE : (kind == OP_END ? W_SHADE : W_OTHER)));
         const unsigned long long m_box = __ballot(want == W_BOX);
         const unsigned long long m_sph = __ballot(want == W_SPHERE);
@@ -815,30 +879,58 @@ __global__ __launch_bounds__(768) void rtk_render_kernel(SceneView<real> sc, con
         }
         const int n_box = int(__builtin_popcountll(m_box)), n_sph = int(__builtin_popcountll(m_sph));
         const int n_oth = int(__builtin_popcountll(m_oth)), n_shd = int(__builtin_popcountll(m_shd));
+        RTK_PROF_MARK(0, 1, n_box + n_sph + n_oth + n_shd)
         if (n_box >= n_sph && n_box >= n_oth && n_box >= n_shd) {
             // Box tests dominate (about 100 per sample against a dozen sphere tests), so
             // the vote is amortised: keep stepping boxes -- one ballot and one branch per
             // step -- until fewer than `keep` lanes are still sitting on a box record.
             const int keep = n_box - (n_box >> 2) > 8 ? n_box - (n_box >> 2) : 8;  // ~3/4 of the lanes that started
-            bool on_box = want == W_BOX;
+            Slot<real> cur = prog[L.pc];  // the record at L.pc, held in registers: one LDS round trip per step
+            uint32_t k = want == W_BOX ? uint32_t(OP_BOX) : uint32_t(OP_END);
+            int remaining;
+            if (__ballot(want == W_BOX && !L.regular) == 0ull) {
+                do {
+                    if (k == OP_BOX) {
+                        step_box<false>(L, cur, cnt);
+                        cur = prog[L.pc];
+                        k = cur.kind_payload & 15u;
+                        L.kind = k;
+                    }
+                    remaining = int(__builtin_popcountll(__ballot(k == OP_BOX)));
+                    RTK_PROF_MARK(1, 1, remaining)
+                } while (remaining >= keep);
+            } else {  // some lane has a ray with a zero/infinite direction component: literal NaN handling for this round
+                do {
+                    if (k == OP_BOX) {
+                        step_box<true>(L, cur, cnt);
+                        cur = prog[L.pc];
+                        k = cur.kind_payload & 15u;
+                        L.kind = k;
+                    }
+                    remaining = int(__builtin_popcountll(__ballot(k == OP_BOX)));
+                } while (remaining >= keep);
+            }
+        } else if (n_sph >= n_oth && n_sph >= n_shd) {
+            // A bvh leaf usually holds two spheres in a row: same amortisation, half the starters.
+            const int keep = (n_sph >> 1) > 8 ? (n_sph >> 1) : 8;
+            Slot<real> cur = prog[L.pc];
+            uint32_t k = want == W_SPHERE ? uint32_t(OP_SPHERE) : uint32_t(OP_END);
             int remaining;
             do {
-                if (on_box) {
-                    step_box(L, *rec, cnt);
-                    rec = prog + L.pc;
-                    on_box = (rec->kind_payload & 15u) == OP_BOX;
+                if (k == OP_SPHERE) {
+                    if (diag & 32u) L.pc += 1;  // timing ablation only (tools/): skip the sphere maths
+                    else step_sphere(L, cur, cnt);
+                    cur = prog[L.pc];
+                    k = cur.kind_payload & 15u;
+                    L.kind = k;
                 }
-                remaining = int(__builtin_popcountll(__ballot(on_box)));
+                remaining = int(__builtin_popcountll(__ballot(k == OP_SPHERE)));
+                RTK_PROF_MARK(2, 1, remaining)
             } while (remaining >= keep);
-        } else if (n_sph >= n_oth && n_sph >= n_shd) {
-            if (want == W_SPHERE) {
-                if (diag & 32u) L.pc += 1;  // timing ablation only (tools/): skip the sphere maths
-                else step_sphere(L, *rec, cnt);
-            }
         } else if (n_shd >= n_oth) {
             if (want == W_SHADE) {
                 if (diag & 16u) L.best_pc = kNoHit;  // timing ablation only (tools/): every segment is treated as a miss
-                const bool ended = L.depth <= 0 || shade<real, FEAT, COUNT>(L, prog, sc, cam, cnt);
+                const bool ended = L.depth <= 0 || shade<real, FEAT, COUNT>(L, prog, sc, mats, cam, cnt);
                 if (ended) {  // pixel_color += ray_color(...) (Camera.txt:72)
                     L.sum = L.sum + L.radiance;
                     L.s += 1;
@@ -852,12 +944,19 @@ __global__ __launch_bounds__(768) void rtk_render_kernel(SceneView<real> sc, con
                 if (alive) {
                     if (L.depth > 0) begin_segment(L, cnt);
                     else L.pc = end_pc;
+                    L.kind = prog[L.pc].kind_payload & 15u;
                 }
             }
+            RTK_PROF_MARK(3, 1, n_shd)
         } else {
-            if (want == W_OTHER) step_other<real, FEAT, COUNT>(L, rec, sc, cnt);
+            if (want == W_OTHER) {
+                step_other<real, FEAT, COUNT>(L, prog + L.pc, sc, cnt);
+                L.kind = prog[L.pc].kind_payload & 15u;
+            }
+            RTK_PROF_MARK(4, 1, n_oth)
         }
     }
+    RTK_PROF_FLUSH
     if constexpr (COUNT) {
 #pragma unroll
         for (int k = 0; k < C_COUNT; k++) {
@@ -942,13 +1041,12 @@ __global__ __launch_bounds__(256) void rtk_unpermute_kernel(const real* __restri
 
 // ------------------------------------------------------------------ launchers --
 constexpr int kLdsBytesPerCU = 160 * 1024;
-constexpr int kMaxWavesPerBlock = 12;  // __launch_bounds__(768)
 
 // Geometry of a persistent launch: waves per workgroup and workgroups per CU so
 // that (a) the register-limited wave count per CU is reached and (b) every
 // resident workgroup's LDS copy of the program fits.
 template <typename Kernel>
-static hipError_t plan_launch(Kernel kernel, size_t lds_bytes, int n_tiles, int& blocks, int& threads) {
+static hipError_t plan_launch(Kernel kernel, int kMaxWavesPerBlock, size_t lds_bytes, int n_tiles, int& blocks, int& threads) {
     int device = 0, cus = 256, waves_per_cu = 0;
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
@@ -975,7 +1073,16 @@ static hipError_t plan_launch(Kernel kernel, size_t lds_bytes, int n_tiles, int&
     const int needed = (n_tiles + waves_per_block - 1) / waves_per_block;
     if (blocks > needed) blocks = needed;
     if (blocks < 1) blocks = 1;
+    if (getenv("RTK_DEBUG"))
+        fprintf(stderr, "[rtk] launch plan: occupancy API %d waves/CU, %d workgroup(s)/CU x %d waves, grid %d x %d threads, LDS %zu B/workgroup\n",
+                waves_per_cu, blocks_per_cu, waves_per_block, blocks, threads, lds_bytes);
     return hipSuccess;
+}
+
+// Bytes a workgroup stages in LDS: the traversal program followed by the material table.
+template <typename real>
+static size_t lds_image_bytes(const SceneView<real>& sc) {
+    return size_t(sc.n_slots) * sizeof(Slot<real>) + size_t(sc.n_materials) * sizeof(MaterialRec<real>);
 }
 
 template <typename real, uint32_t FEAT, bool COUNT, bool IN_LDS>
@@ -984,9 +1091,9 @@ static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>* c
     const int n_items = tmap.n_tiles_local * tmap.n_chunks;
     if (n_items <= 0) return hipSuccess;
     auto kernel = rtk_render_kernel<real, FEAT, COUNT, IN_LDS>;
-    const size_t lds = IN_LDS ? size_t(sc.n_slots) * sizeof(Slot<real>) : 0;
+    const size_t lds = IN_LDS ? lds_image_bytes(sc) : 0;
     int blocks = 0, threads = 0;
-    hipError_t e = plan_launch(kernel, lds, n_items, blocks, threads);
+    hipError_t e = plan_launch(kernel, max_threads<real, FEAT>() / 64, lds, n_items, blocks, threads);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(tile_counter, 0, sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
@@ -996,7 +1103,7 @@ static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>* c
 
 template <typename real>
 bool program_fits_lds(const SceneView<real>& sc) {
-    return size_t(sc.n_slots) * sizeof(Slot<real>) <= size_t(kLdsBytesPerCU);
+    return lds_image_bytes(sc) <= size_t(kLdsBytesPerCU);
 }
 
 template <typename real>

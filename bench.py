@@ -56,6 +56,8 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-f32", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
+    p.add_argument("--rehearse-one-gpu", action="store_true",
+                   help="dev only: run all ranks on device 0 with a gloo gather through host memory, to rehearse the N>1 control flow on a 1-GPU box")
     return p.parse_args()
 
 
@@ -118,11 +120,16 @@ def main():
         n = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists for the product)")
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if n > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=n, device_id=dev)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=n)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=n, device_id=dev)
 
     # ---- inputs: scene + camera, resident in HBM before anything is timed
     scene_name = rt.CONFIG_SCENES[args.config]
@@ -155,7 +162,11 @@ def main():
             if kernel_ms is not None:
                 ev[1].record()
             if n > 1:
-                gathered = tiling.gather_to_root(compact, n, rank)
+                if args.rehearse_one_gpu:  # gloo has no device gather: stage through host memory (rehearsal only)
+                    host = tiling.gather_to_root(compact.cpu(), n, rank)
+                    gathered = host.to(dev) if rank == 0 else None
+                else:
+                    gathered = tiling.gather_to_root(compact, n, rank)
                 if rank == 0:
                     renderer.unpermute(W, H, n, real_mode, gathered.data_ptr(), image.data_ptr(), rgb8.data_ptr(), stream=stream)
             if kernel_ms is not None:
@@ -190,6 +201,10 @@ def main():
         return elapsed, sum(kernel_ms) / len(kernel_ms), image
 
     elapsed, kernel_ms, image = timed(rt.RTK_REAL_F64, args.steps, args.warmup)
+    checksum = None
+    if rank == 0:  # a digest of the framebuffer: must not depend on the number of GPUs
+        import hashlib
+        checksum = hashlib.sha256(image.cpu().numpy().tobytes()).hexdigest()[:16]
     samples_per_step = W * H * spp
     value = samples_per_step * args.steps / elapsed / 1e6
 
@@ -206,19 +221,28 @@ def main():
         b_sample = rt.algorithmic_bytes_per_sample(counters, spp, rt.RTK_REAL_F64)
         bytes_per_launch = b_sample * counters["samples"]
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM traffic and instruction counts come from separate rocprofv3 --pmc passes (tools/pmc_profile.sh),
+        # committed under profiles/; they are quoted only when they were taken on this exact workload.
+        traffic, issue = None, None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
                 rec = json.load(open(tfile))
                 if rec.get("workload") == f"{scene_name} {W}x{H}x{spp}" and rec.get("n_gpus") == n and rec.get("dtype") == "f64":
                     traffic = rec.get("hbm_bytes_per_launch")
+                    # what actually bounds the kernel: VALU instruction issue (one wave-instruction per SIMD per
+                    # ~4 cycles for this f64/select mix), on partially filled waves
+                    simd_cycles = kernel_ms * 1e-3 * 2.4e9 * 1024
+                    issue = {"valu_insts_per_launch": int(rec["SQ_INSTS_VALU"]), "f64_share": round(rec["SQ_INSTS_VALU_F64"] / rec["SQ_INSTS_VALU"], 3),
+                             "valu_lane_utilisation": rec["valu_lane_utilisation"],
+                             "simd_issue_frac_at_4_cycles_per_inst": round(rec["SQ_INSTS_VALU"] * 4 / simd_cycles, 3), "source": "profiles/pmc_traffic.json"}
             except Exception:
-                traffic = None
+                traffic, issue = None, None
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "kernel": renderer.kernel_name(rt.RTK_REAL_F64, args.variant), "kernel_ms": round(kernel_ms, 4),
                     "algorithmic_bytes_per_sample": round(b_sample, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                    "compulsory_bytes": info["bytes_f64"] + W * H * 3 * 9,
+                    "compulsory_bytes": info["bytes_f64"] + W * H * 3 * 9, "valu_issue": issue,
+                    "note": "achieved = algorithmic bytes (SURVEY 8(d) model x exact counters) / kernel time; the program is served from LDS, so frac can exceed 1 -- see DESIGN.md section 5",
                     "per_sample": {k: round(counters[k] / counters["samples"], 4) for k in rt.COUNTER_FIELDS if k != "samples"}}
 
     f32_mode = None
@@ -249,6 +273,7 @@ def main():
             "cpu_baseline": cpu,
             "f32_mode": f32_mode,
             "speedup_vs_cpu_baseline": (round(value / cpu["value"], 1) if cpu and cpu.get("value") else None),
+            "framebuffer_sha256": checksum,
         }
         print(json.dumps(line), flush=True)
     if n > 1:

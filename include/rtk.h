@@ -271,6 +271,17 @@ int rtk_tiles_unpermute(rtk_ctx* ctx, int image_width, int image_height, int n_r
 int rtk_render_host(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts* opts,
                     double* h_linear, uint8_t* h_rgb8, rtk_work_counters* counters);
 
+/* Known-answer / diagnostic entry point: hittable::hit(r, interval(tmin, tmax), rec) of the uploaded
+ * scene's root (hittable.h:33) for n caller-supplied rays, run through the same device traversal and
+ * hit-record code as the render kernel.  Host buffers:
+ *   h_rays [n][9] = origin(3), direction(3), time, tmin, tmax
+ *   h_keys [n][3] = seed, pixel, sample of the RNG stream a constant_medium draws from (constant_medium.h:40)
+ *   h_out  [n][12] = hit(0/1), t, p(3), normal(3), front_face, u, v, material index (-1 on a miss)
+ *   h_draws[n]     = random_double() calls consumed
+ * Blocking; not a rendering path. */
+int rtk_debug_closest_hit(rtk_ctx* ctx, int real_mode, int n, const double* h_rays, const uint32_t* h_keys,
+                          double* h_out, uint64_t* h_draws);
+
 /* Introspection of the uploaded scene's traversal program (for tests and
  * for the byte model): number of program slots (fused records) and device bytes per mode. */
 int rtk_scene_info(rtk_ctx* ctx, int32_t* n_program_ops, int64_t* bytes_f64, int64_t* bytes_f32);

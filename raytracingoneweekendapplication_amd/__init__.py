@@ -153,6 +153,7 @@ def hip_lib() -> C.CDLL:
         lib.rtk_tiles_unpermute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rtk_render_host.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rtk_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        lib.rtk_debug_closest_hit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rtk_kernel_name.restype = C.c_char_p
         lib.rtk_kernel_name.argtypes = [C.c_void_p, C.c_int, C.c_int]
         if lib.rtk_abi_version() != RTK_ABI_VERSION:
@@ -278,6 +279,19 @@ class Renderer:
         self._check(self._lib.rtk_render_host(self._ctx, C.byref(cam), C.byref(opts), linear.ctypes.data, rgb8.ctypes.data,
                                               C.byref(counters) if count else None))
         return linear, rgb8, (counters.as_dict() if count else None)
+
+    def closest_hit(self, rays, keys, real_mode: int = RTK_REAL_F64):
+        """Known-answer helper: hittable::hit of the scene root for rays [n,9] (o, d, time, tmin, tmax) with RNG keys
+        [n,3] (seed, pixel, sample).  Returns (records [n,12], draws [n])."""
+        import numpy as np
+
+        rays = np.ascontiguousarray(rays, np.float64)
+        keys = np.ascontiguousarray(keys, np.uint32)
+        n = rays.shape[0]
+        out = np.zeros((n, 12), np.float64)
+        draws = np.zeros(n, np.uint64)
+        self._check(self._lib.rtk_debug_closest_hit(self._ctx, real_mode, n, rays.ctypes.data, keys.ctypes.data, out.ctypes.data, draws.ctypes.data))
+        return out, draws
 
     def close(self) -> None:
         if getattr(self, "_ctx", None):

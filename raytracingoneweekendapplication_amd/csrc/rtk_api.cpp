@@ -702,6 +702,37 @@ int rtk_render_host(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts* 
     return RTK_OK;
 }
 
+int rtk_debug_closest_hit(rtk_ctx* ctx, int real_mode, int n, const double* h_rays, const uint32_t* h_keys, double* h_out, uint64_t* h_draws) {
+    if (!ctx || n < 0 || !h_rays || !h_keys || !h_out || !h_draws) return fail(RTK_ERR_INVALID, "rtk_debug_closest_hit: bad argument");
+    if (!ctx->has_scene) return fail(RTK_ERR_NO_SCENE, "rtk_debug_closest_hit: no scene uploaded");
+    if (n == 0) return RTK_OK;
+    RTK_HIP(hipSetDevice(ctx->device));
+    double *d_rays = nullptr, *d_out = nullptr;
+    uint32_t* d_keys = nullptr;
+    unsigned long long* d_draws = nullptr;
+    auto cleanup = [&]() {
+        if (d_rays) (void)hipFree(d_rays);
+        if (d_out) (void)hipFree(d_out);
+        if (d_keys) (void)hipFree(d_keys);
+        if (d_draws) (void)hipFree(d_draws);
+    };
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_rays), size_t(n) * 9 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_out), size_t(n) * 12 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_keys), size_t(n) * 3 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_draws), size_t(n) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemcpy(d_rays, h_rays, size_t(n) * 9 * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_keys, h_keys, size_t(n) * 3 * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = real_mode == RTK_REAL_F64 ? launch_debug_hit<double>(ctx->scene64.view, n, d_rays, d_keys, d_out, d_draws, nullptr)
+                                      : launch_debug_hit<float>(ctx->scene32.view, n, d_rays, d_keys, d_out, d_draws, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(h_out, d_out, size_t(n) * 12 * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(h_draws, d_draws, size_t(n) * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail(RTK_ERR_HIP, "rtk_debug_closest_hit: %s", hipGetErrorString(e));
+    return RTK_OK;
+}
+
 int rtk_scene_info(rtk_ctx* ctx, int32_t* n_program_ops, int64_t* bytes_f64, int64_t* bytes_f32) {
     if (!ctx || !ctx->has_scene) return fail(RTK_ERR_NO_SCENE, "rtk_scene_info: no scene uploaded");
     if (n_program_ops) *n_program_ops = ctx->scene64.view.n_slots;

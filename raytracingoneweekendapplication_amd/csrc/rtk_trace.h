@@ -28,6 +28,11 @@ hipError_t launch_resolve(const void* partial, const TileMap& tmap, int width, i
 template <typename real>
 bool program_fits_lds(const SceneView<real>& sc);
 
+// Known-answer helper: closest hit of the scene root for n caller-supplied rays (device buffers).
+template <typename real>
+hipError_t launch_debug_hit(const SceneView<real>& sc, int n, const double* d_rays, const uint32_t* d_keys, double* d_out, unsigned long long* d_draws,
+                            hipStream_t stream);
+
 template <typename real>
 hipError_t launch_unpermute(const void* gathered, int width, int height, int n_ranks, long long tiles_per_rank, void* out_linear, uint8_t* out_rgb8,
                             hipStream_t stream);

@@ -528,7 +528,7 @@ struct Surface {  // hit_record (hittable.h:11-27)
 // triangles go to their side record for the normal and the UVs.
 template <typename real, uint32_t FEAT>
 RTK_DEV void make_surface(const Slot<real>* __restrict__ prog, const SceneView<real>& sc, const MaterialRec<real>* __restrict__ mats, uint32_t best_pc, real t,
-                          V3<real> wo, V3<real> wd, real tm, Surface<real>& sf) {
+                          V3<real> wo, V3<real> wd, real tm, Surface<real>& sf, bool force_uv = false) {
     const Slot<real>* rec = prog + best_pc;
     const uint32_t kind = rec->kind_payload & 15u;
     const uint32_t idx = rec->kind_payload >> 4;
@@ -545,7 +545,7 @@ RTK_DEV void make_surface(const Slot<real>* __restrict__ prog, const SceneView<r
         V3<real> cc = mk(rec->v[0], rec->v[1], rec->v[2]);
         if (kind == OP_SPHERE_MOVING) cc = cc + scale(tm, mk(rec[1].v[0], rec[1].v[1], rec[1].v[2]));
         outward = divide(sf.p - cc, rec->v[3]);
-        if ((FEAT & F_TEXTURE) && mats[sf.material].needs_uv) {
+        if ((FEAT & F_TEXTURE) && (force_uv || mats[sf.material].needs_uv)) {
             const real pi = real(3.1415926535897932385);
             real theta = rt_acos(-outward.y);
             real phi = rt_atan2(-outward.z, outward.x) + pi;
@@ -967,6 +967,58 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
     }
 }
 
+// Known-answer entry point (tests): hittable::hit(r, interval(tmin, tmax), rec) of the uploaded scene's
+// root for caller-supplied rays, one lane per ray, lock-step over the traversal program.  Exercises the same
+// step_* / make_surface code as the render kernel.  out[12] = hit, t, p(3), normal(3), front_face, u, v, material.
+template <typename real>
+__global__ __launch_bounds__(256) void rtk_debug_hit_kernel(SceneView<real> sc, int n, const double* __restrict__ rays, const uint32_t* __restrict__ keys,
+                                                             double* __restrict__ out, unsigned long long* __restrict__ draws) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n) return;
+    const double* r = rays + size_t(gid) * 9;
+    Counters<true> cnt;
+    cnt.clear();
+    Lane<real> L;
+    L.ro = mk(real(r[0]), real(r[1]), real(r[2]));
+    L.rd = mk(real(r[3]), real(r[4]), real(r[5]));
+    L.tm = real(r[6]);
+    L.rng = pcg_hash(keys[gid * 3 + 1] + pcg_hash(keys[gid * 3 + 2] + pcg_hash(keys[gid * 3])));
+    L.sv_tmin = L.sv_best_t = L.rec1_t = real(0);
+    L.sv_best_pc = kNoHit;
+    begin_segment(L, cnt);
+    L.tmin = real(r[7]);
+    L.best_t = real(r[8]);
+    const Slot<real>* prog = sc.program;
+    for (;;) {
+        const Slot<real>* rec = prog + L.pc;
+        const uint32_t kind = rec->kind_payload & 15u;
+        if (kind == OP_END) break;
+        if (kind == OP_BOX) {
+            if (L.regular) step_box<false>(L, *rec, cnt);
+            else step_box<true>(L, *rec, cnt);
+        } else if (kind == OP_SPHERE) {
+            step_sphere(L, *rec, cnt);
+        } else {
+            step_other<real, kFeatAll, true>(L, rec, sc, cnt);
+        }
+    }
+    double* o = out + size_t(gid) * 12;
+    for (int k = 0; k < 12; k++) o[k] = 0.0;
+    o[11] = -1.0;
+    if (L.best_pc != kNoHit) {
+        Surface<real> sf;
+        make_surface<real, kFeatAll>(prog, sc, sc.materials, L.best_pc, L.best_t, L.ro, L.rd, L.tm, sf, true);
+        o[0] = 1.0;
+        o[1] = double(L.best_t);
+        o[2] = double(sf.p.x); o[3] = double(sf.p.y); o[4] = double(sf.p.z);
+        o[5] = double(sf.normal.x); o[6] = double(sf.normal.y); o[7] = double(sf.normal.z);
+        o[8] = sf.front_face ? 1.0 : 0.0;
+        o[9] = double(sf.u); o[10] = double(sf.v);
+        o[11] = double(sf.material);
+    }
+    draws[gid] = cnt.c[C_RNG];
+}
+
 // Partial sums -> pixels.  For every pixel of this rank: add its chunks in index
 // order, scale by 1/spp (Camera.txt:74) and write either the row-major image
 // (+ gamma/clamp/quantised bytes, Camera.txt:77-89) or this rank's compact tile
@@ -1135,6 +1187,16 @@ hipError_t launch_resolve(const void* partial, const TileMap& tmap, int width, i
 }
 template hipError_t launch_resolve<double>(const void*, const TileMap&, int, int, double, void*, uint8_t*, hipStream_t);
 template hipError_t launch_resolve<float>(const void*, const TileMap&, int, int, double, void*, uint8_t*, hipStream_t);
+
+template <typename real>
+hipError_t launch_debug_hit(const SceneView<real>& sc, int n, const double* d_rays, const uint32_t* d_keys, double* d_out, unsigned long long* d_draws,
+                            hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    rtk_debug_hit_kernel<real><<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(sc, n, d_rays, d_keys, d_out, d_draws);
+    return hipGetLastError();
+}
+template hipError_t launch_debug_hit<double>(const SceneView<double>&, int, const double*, const uint32_t*, double*, unsigned long long*, hipStream_t);
+template hipError_t launch_debug_hit<float>(const SceneView<float>&, int, const double*, const uint32_t*, double*, unsigned long long*, hipStream_t);
 
 template <typename real>
 hipError_t launch_unpermute(const void* gathered, int width, int height, int n_ranks, long long tiles_per_rank, void* out_linear, uint8_t* out_rgb8,

@@ -25,21 +25,9 @@
 #include <unordered_map>
 #include <vector>
 
+#include "glm_min.h"  // glm::vec2 for triangle UVs (triangle.h:137-139); the full GLM is not a dependency
 #include "rtk.h"
 #include "rtk_math.h"
-
-namespace glm {
-// The reference stores triangle UVs as glm::vec2 (triangle.h:137-139).  Two
-// floats are all the hot path needs; the full GLM is not a dependency.  If the
-// real GLM was included first, its types are used instead.
-#ifndef GLM_VERSION
-struct vec2 {
-    float x, y;
-    vec2() : x(0), y(0) {}
-    vec2(float a, float b) : x(a), y(b) {}
-};
-#endif
-}  // namespace glm
 
 namespace rtk {
 

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "camera.h"
+#include "mesh.h"
 #include "rtk_desc_io.h"
 #include "scenes/scene_library.h"
 

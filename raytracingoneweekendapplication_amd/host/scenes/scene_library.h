@@ -249,6 +249,28 @@ inline void rtk_scene_book2_final(rtk_scene_def& s, const char* earth_image) {
     s.view.defocus_angle = 0; s.view.focus_dist = 10;
 }
 
+// C4 with a real asset: an OBJ file loaded through mesh::loadObj (mesh.h:22) under a rotate/scale/translate
+// transform, as main.cpp:399-412 does for its (missing) corgi model.  `obj_file` is e.g. the reference's
+// monkey.obj (968 triangles) where that file is available; tests also use a small hand-written OBJ.
+inline void rtk_scene_obj_mesh(rtk_scene_def& s, const char* obj_file) {
+    auto grey = make_shared<lambertian>(color(0.5, 0.5, 0.5));
+    auto clay = make_shared<lambertian>(color(0.7, 0.35, 0.2));
+    glm::mat4 transform = glm::mat4(1.0f);
+    transform = glm::translate(transform, glm::vec3(0.25f, 0.1f, -0.5f));
+    transform = glm::rotate(transform, glm::radians(30.0f), glm::vec3(0, 1, 0));
+    transform = glm::scale(transform, glm::vec3(1.2f, 1.2f, 1.2f));
+    mesh model;
+    if (!model.loadObj(obj_file, s.world, clay, transform)) s.world.add(make_shared<sphere>(point3(0, 0, 0), 1.0, clay));
+    s.world.add(make_shared<sphere>(point3(0, -1001.3, 0), 1000, grey));
+    s.world.add(make_shared<sphere>(point3(2.5, 4, 2), 1.5, make_shared<diffuse_light>(color(12, 12, 12))));
+    rtk_wrap_in_bvh(s);
+    s.view.image_width = 1920; s.view.image_height = 1080;
+    s.view.samples_per_pixel = 256; s.view.max_depth = 10;
+    s.view.background = color(0.05, 0.06, 0.10);
+    s.view.vfov = 40; s.view.lookfrom = point3(1.5, 1, 4); s.view.lookat = point3(0, 0, 0);
+    s.view.defocus_angle = 0; s.view.focus_dist = 10;
+}
+
 // ---- parity-test scenes (small, cover what the configs do not) -------------
 
 // Every material and every texture kind, triangles with UVs, a point light pair.
@@ -332,6 +354,7 @@ inline bool rtk_build_named_scene(const char* name, const char* image_file, rtk_
     else if (n == "material_zoo") rtk_scene_material_zoo(s, image_file);
     else if (n == "cornell_smoke") rtk_scene_cornell_smoke(s);
     else if (n == "single_fog") rtk_scene_single_fog(s);
+    else if (n == "obj_mesh") rtk_scene_obj_mesh(s, image_file);  // the file argument is the OBJ path here
     else return false;
     return true;
 }

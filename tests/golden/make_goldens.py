@@ -23,7 +23,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
-from tests.scene_cases import IMAGE_CASES, SCENE_SEED, RENDER_SEED  # noqa: E402
+from tests.scene_cases import IMAGE_CASES, SCENE_SEED, RENDER_SEED, scene_file  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
 
@@ -45,10 +45,12 @@ def main():
     hashes = {}
     for name, W, H, spp, depth in IMAGE_CASES:
         desc = os.path.join(tmp, name + ".rtks")
-        subprocess.check_call([REF, "desc", name, str(SCENE_SEED), earth, desc])
+        arg = scene_file(name, HERE)
+        subprocess.check_call([REF, "desc", name, str(SCENE_SEED), arg, desc], stderr=subprocess.DEVNULL)
         hashes[name] = hashlib.sha256(open(desc, "rb").read()).hexdigest()
         prefix = os.path.join(tmp, "img_" + name)
-        subprocess.check_call([REF, "render", name, str(SCENE_SEED), earth, str(W), str(H), str(spp), str(depth), str(RENDER_SEED), "4", prefix])
+        subprocess.check_call([REF, "render", name, str(SCENE_SEED), arg, str(W), str(H), str(spp), str(depth), str(RENDER_SEED), "4", prefix],
+                              stderr=subprocess.DEVNULL)
         meta = json.load(open(prefix + ".json"))
         np.savez_compressed(os.path.join(HERE, f"img_{name}.npz"),
                             linear=np.fromfile(prefix + ".f64").reshape(H, W, 3), rgb8=np.fromfile(prefix + ".u8", np.uint8).reshape(H, W, 3),

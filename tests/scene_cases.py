@@ -12,4 +12,15 @@ IMAGE_CASES = [
     ("material_zoo", 96, 54, 8, 12),
     ("cornell_smoke", 48, 48, 8, 10),
     ("single_fog", 48, 32, 16, 8),
+    ("obj_mesh", 64, 36, 4, 10),
 ]
+
+# File argument of rtk_build_named_scene per scene (relative to tests/golden/): the texture image for the
+# textured scenes, the OBJ path for obj_mesh.
+SCENE_FILES = {"obj_mesh": "quad_tri.obj"}
+
+
+def scene_file(name, golden_dir):
+    import os
+
+    return os.path.join(golden_dir, SCENE_FILES.get(name, "earth_synth.ppm"))

@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 
 from tests.conftest import EARTH, GOLDEN
-from tests.scene_cases import IMAGE_CASES, RENDER_SEED, SCENE_SEED
+from tests.scene_cases import IMAGE_CASES, RENDER_SEED, SCENE_SEED, scene_file
 
 pytestmark = pytest.mark.gpu
 
@@ -36,7 +36,7 @@ def scenes(rt):
 
     def get(name):
         if name not in cache:
-            cache[name] = rt.Scene.build(name, SCENE_SEED, EARTH)
+            cache[name] = rt.Scene.build(name, SCENE_SEED, scene_file(name, GOLDEN))
         return cache[name]
     return get
 

@@ -733,6 +733,10 @@ RTK_DEV uint8_t to_byte(double x) {  // Camera.txt:29-34,77-83
 // bit-identical to a lock-step execution.
 enum Want : int { W_DONE = 0, W_BOX = 1, W_SPHERE = 2, W_OTHER = 3, W_SHADE = 4 };
 
+// Lane count of a ballot as a 32-bit scalar (two s_bcnt1_i32_b32 + s_add): with the 64-bit builtin the
+// compiler carries the count as i64 and does the vote's comparisons on the vector unit.
+RTK_DEV int popcount64(unsigned long long m) { return __builtin_popcount(uint32_t(m)) + __builtin_popcount(uint32_t(m >> 32)); }
+
 // Diagnostic build only (tools/profile_phases.py compiles this file with -DRTK_PROFILE into a separate
 // library): s_memtime stamps at the scheduler's phase boundaries; per phase the wave adds its cycles,
 // step count and active-lane count to counters[3*phase .. 3*phase+2].  The product build has none of it.
@@ -860,7 +864,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                     L.kind = prog[L.pc].kind_payload & 15u;
                 }
             }
-            const int n_idle = int(__builtin_popcountll(m_idle));
+            const int n_idle = popcount64(m_idle);
             refill_next += n_idle < avail ? n_idle : avail;
             m_idle = __ballot(!alive);
             if (n_idle <= avail) break;  // every idle lane was offered a pixel this round (some fell outside the image)
@@ -877,14 +881,18 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             if (exhausted) break;
             continue;
         }
-        const int n_box = int(__builtin_popcountll(m_box)), n_sph = int(__builtin_popcountll(m_sph));
-        const int n_oth = int(__builtin_popcountll(m_oth)), n_shd = int(__builtin_popcountll(m_shd));
+        const int n_box = popcount64(m_box), n_sph = popcount64(m_sph), n_oth = popcount64(m_oth), n_shd = popcount64(m_shd);
         RTK_PROF_MARK(0, 1, n_box + n_sph + n_oth + n_shd)
         if (n_box >= n_sph && n_box >= n_oth && n_box >= n_shd) {
             // Box tests dominate (about 100 per sample against a dozen sphere tests), so
             // the vote is amortised: keep stepping boxes -- one ballot and one branch per
-            // step -- until fewer than `keep` lanes are still sitting on a box record.
-            const int keep = n_box - (n_box >> 2) > 8 ? n_box - (n_box >> 2) : 8;  // ~3/4 of the lanes that started
+            // step -- until fewer than `keep` lanes are still sitting on a box record.  A low
+            // threshold wins: leaving the loop costs a vote plus an exposed LDS round trip,
+            // which is worth more than the lanes that idle for a few extra steps.
+            const int sel = int(diag >> 8) & 7;  // tools/: A/B of the loop-exit threshold, in eighths of the starters (0 = default)
+            const int eighths = sel == 0 ? 3 : sel;  // measured on C2: 3/8 of the starters is the sweet spot (2/8..4/8 within 1 %)
+            const int frac = (n_box * eighths) >> 3;
+            const int keep = frac > 8 ? frac : 8;
             Slot<real> cur = prog[L.pc];  // the record at L.pc, held in registers: one LDS round trip per step
             uint32_t k = want == W_BOX ? uint32_t(OP_BOX) : uint32_t(OP_END);
             int remaining;
@@ -896,7 +904,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                         k = cur.kind_payload & 15u;
                         L.kind = k;
                     }
-                    remaining = int(__builtin_popcountll(__ballot(k == OP_BOX)));
+                    remaining = popcount64(__ballot(k == OP_BOX));
                     RTK_PROF_MARK(1, 1, remaining)
                 } while (remaining >= keep);
             } else {  // some lane has a ray with a zero/infinite direction component: literal NaN handling for this round
@@ -907,12 +915,14 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                         k = cur.kind_payload & 15u;
                         L.kind = k;
                     }
-                    remaining = int(__builtin_popcountll(__ballot(k == OP_BOX)));
+                    remaining = popcount64(__ballot(k == OP_BOX));
                 } while (remaining >= keep);
             }
         } else if (n_sph >= n_oth && n_sph >= n_shd) {
             // A bvh leaf usually holds two spheres in a row: same amortisation, half the starters.
-            const int keep = (n_sph >> 1) > 8 ? (n_sph >> 1) : 8;
+            const int ssel = int(diag >> 11) & 7;  // tools/: same for the sphere loop (0 = default)
+            const int sfrac = (n_sph * (ssel == 0 ? 4 : ssel)) >> 3;
+            const int keep = sfrac > 8 ? sfrac : 8;
             Slot<real> cur = prog[L.pc];
             uint32_t k = want == W_SPHERE ? uint32_t(OP_SPHERE) : uint32_t(OP_END);
             int remaining;
@@ -924,7 +934,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                     k = cur.kind_payload & 15u;
                     L.kind = k;
                 }
-                remaining = int(__builtin_popcountll(__ballot(k == OP_SPHERE)));
+                remaining = popcount64(__ballot(k == OP_SPHERE));
                 RTK_PROF_MARK(2, 1, remaining)
             } while (remaining >= keep);
         } else if (n_shd >= n_oth) {

@@ -731,11 +731,15 @@ RTK_DEV uint8_t to_byte(double x) {  // Camera.txt:29-34,77-83
 // waits for the longest path in the wave.  Scheduling changes only the
 // interleaving between lanes, never a lane's own arithmetic, so the image is
 // bit-identical to a lock-step execution.
-enum Want : int { W_DONE = 0, W_BOX = 1, W_SPHERE = 2, W_OTHER = 3, W_SHADE = 4 };
+enum Want : int { W_DONE = 0, W_BOX = 1, W_SPHERE = 2, W_OTHER = 3, W_SHADE = 4, W_QUAD = 5, W_TRI = 6 };
 
-// Lane count of a ballot as a 32-bit scalar (two s_bcnt1_i32_b32 + s_add): with the 64-bit builtin the
-// compiler carries the count as i64 and does the vote's comparisons on the vector unit.
-RTK_DEV int popcount64(unsigned long long m) { return __builtin_popcount(uint32_t(m)) + __builtin_popcount(uint32_t(m >> 32)); }
+// Lane count of a ballot as a 32-bit scalar, one s_bcnt1_i32_b64.  With __builtin_popcountll the compiler
+// carries the count as i64 and performs the vote's comparisons on the vector unit (v_cmp_lt_u64).
+RTK_DEV int popcount64(unsigned long long m) {
+    int n;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc");
+    return n;
+}
 
 // Diagnostic build only (tools/profile_phases.py compiles this file with -DRTK_PROFILE into a separate
 // library): s_memtime stamps at the scheduler's phase boundaries; per phase the wave adds its cycles,
@@ -872,18 +876,36 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
 
         // ---- vote (registers and scalar unit only)
         const uint32_t kind = L.kind;
-        const int want = !alive ? W_DONE : (kind == OP_BOX ? W_BOX : (kind == OP_SPHERE ? W_SPHERE : (kind == OP_END ? W_SHADE : W_OTHER)));
+        int want = W_DONE;
+        if (alive) {
+            want = kind == OP_BOX ? W_BOX : (kind == OP_SPHERE ? W_SPHERE : (kind == OP_END ? W_SHADE : W_OTHER));
+            if ((FEAT & F_QUAD) && kind == OP_QUAD) want = W_QUAD;
+            if ((FEAT & F_TRI) && kind == OP_TRI) want = W_TRI;
+        }
         const unsigned long long m_box = __ballot(want == W_BOX);
         const unsigned long long m_sph = __ballot(want == W_SPHERE);
         const unsigned long long m_oth = __ballot(want == W_OTHER);
         const unsigned long long m_shd = __ballot(want == W_SHADE);
-        if ((m_box | m_sph | m_oth | m_shd) == 0ull) {
+        const unsigned long long m_quad = (FEAT & F_QUAD) ? __ballot(want == W_QUAD) : 0ull;
+        const unsigned long long m_tri = (FEAT & F_TRI) ? __ballot(want == W_TRI) : 0ull;
+        if ((m_box | m_sph | m_oth | m_shd | m_quad | m_tri) == 0ull) {
             if (exhausted) break;
             continue;
         }
         const int n_box = popcount64(m_box), n_sph = popcount64(m_sph), n_oth = popcount64(m_oth), n_shd = popcount64(m_shd);
-        RTK_PROF_MARK(0, 1, n_box + n_sph + n_oth + n_shd)
-        if (n_box >= n_sph && n_box >= n_oth && n_box >= n_shd) {
+        const int n_quad = popcount64(m_quad), n_tri = popcount64(m_tri);
+        RTK_PROF_MARK(0, 1, n_box + n_sph + n_oth + n_shd + n_quad + n_tri)
+        // The kind with the most ready lanes wins; ties go to the cheaper kind (order of the tests).  Written as
+        // nested comparisons on purpose: a running "pick/most" update chain compiled to a 9 % slower kernel
+        // (tools/ab/run_ab.sh A/B on the same box: 78.5 ms vs 70.2 ms per C2 frame).
+        int pick;
+        if (n_box >= n_sph && n_box >= n_quad && n_box >= n_tri && n_box >= n_shd && n_box >= n_oth) pick = W_BOX;
+        else if (n_sph >= n_quad && n_sph >= n_tri && n_sph >= n_shd && n_sph >= n_oth) pick = W_SPHERE;
+        else if (n_quad >= n_tri && n_quad >= n_shd && n_quad >= n_oth) pick = W_QUAD;
+        else if (n_tri >= n_shd && n_tri >= n_oth) pick = W_TRI;
+        else if (n_shd >= n_oth) pick = W_SHADE;
+        else pick = W_OTHER;
+        if (pick == W_BOX) {
             // Box tests dominate (about 100 per sample against a dozen sphere tests), so
             // the vote is amortised: keep stepping boxes -- one ballot and one branch per
             // step -- until fewer than `keep` lanes are still sitting on a box record.  A low
@@ -918,7 +940,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                     remaining = popcount64(__ballot(k == OP_BOX));
                 } while (remaining >= keep);
             }
-        } else if (n_sph >= n_oth && n_sph >= n_shd) {
+        } else if (pick == W_SPHERE) {
             // A bvh leaf usually holds two spheres in a row: same amortisation, half the starters.
             const int ssel = int(diag >> 11) & 7;  // tools/: same for the sphere loop (0 = default)
             const int sfrac = (n_sph * (ssel == 0 ? 4 : ssel)) >> 3;
@@ -937,7 +959,48 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                 remaining = popcount64(__ballot(k == OP_SPHERE));
                 RTK_PROF_MARK(2, 1, remaining)
             } while (remaining >= keep);
-        } else if (n_shd >= n_oth) {
+        } else if ((FEAT & F_QUAD) && pick == W_QUAD) {
+            // quad::hit.  A box() is six quads in a row (quad.h:86-108): stay while at least half the starters do.
+            const int keep = (n_quad >> 1) > 8 ? (n_quad >> 1) : 8;
+            uint32_t k = want == W_QUAD ? uint32_t(OP_QUAD) : uint32_t(OP_END);
+            int remaining;
+            do {
+                if (k == OP_QUAD) {
+                    cnt.inc(C_QUAD);
+                    real t, al, be;
+                    if (quad_test(prog + L.pc, L.o, L.d, L.tmin, L.best_t, t, al, be)) {
+                        L.best_t = t;
+                        L.best_pc = L.pc;
+                    }
+                    L.pc += 3;
+                    k = prog[L.pc].kind_payload & 15u;
+                    L.kind = k;
+                }
+                remaining = popcount64(__ballot(k == OP_QUAD));
+                RTK_PROF_MARK(5, 1, remaining)
+            } while (remaining >= keep);
+        } else if ((FEAT & F_TRI) && pick == W_TRI) {
+            // triangle::hit; a bvh leaf holds one or two triangles.
+            const int keep = (n_tri >> 1) > 8 ? (n_tri >> 1) : 8;
+            uint32_t k = want == W_TRI ? uint32_t(OP_TRI) : uint32_t(OP_END);
+            int remaining;
+            do {
+                if (k == OP_TRI) {
+                    cnt.inc(C_TRI);
+                    real t;
+                    float fa, fb, fg;
+                    if (tri_test(prog + L.pc, L.o, L.d, L.tmin, L.best_t, t, fa, fb, fg)) {
+                        L.best_t = t;
+                        L.best_pc = L.pc;
+                    }
+                    L.pc += 2;
+                    k = prog[L.pc].kind_payload & 15u;
+                    L.kind = k;
+                }
+                remaining = popcount64(__ballot(k == OP_TRI));
+                RTK_PROF_MARK(5, 1, remaining)
+            } while (remaining >= keep);
+        } else if (pick == W_SHADE) {
             if (want == W_SHADE) {
                 if (diag & 16u) L.best_pc = kNoHit;  // timing ablation only (tools/): every segment is treated as a miss
                 const bool ended = L.depth <= 0 || shade<real, FEAT, COUNT>(L, prog, sc, mats, cam, cnt);

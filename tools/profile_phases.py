@@ -44,7 +44,7 @@ for k in range(2):
 ms = e0.elapsed_time(e1)
 v = prof.cpu().numpy().reshape(6, 3).astype(float)
 total = v[:, 0].sum()
-names = ["refill+vote", "box step", "sphere step", "shade+regen", "other op", "-"]
+names = ["refill+vote", "box step", "sphere step", "shade+regen", "other op", "quad/tri step"]
 print(f"{config} {'f64' if real == rt.RTK_REAL_F64 else 'f32'} {W}x{H}x{cam.samples_per_pixel}: {ms:.2f} ms (instrumented)")
 print(f"{'phase':14s} {'cycles %':>9s} {'steps':>14s} {'cyc/step':>9s} {'lanes/step':>10s}")
 for n, (t, steps, lanes) in zip(names, v):

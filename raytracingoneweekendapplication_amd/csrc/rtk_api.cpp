@@ -579,8 +579,8 @@ int64_t rtk_tiles_per_rank(int image_width, int image_height, int n_ranks) {
 int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts* opts, void* d_linear, uint8_t* d_rgb8, rtk_work_counters* d_counters) {
     if (!ctx || !cam || !opts) return fail(RTK_ERR_INVALID, "rtk_render_device: null argument");
     if (!ctx->has_scene) return fail(RTK_ERR_NO_SCENE, "rtk_render_device: no scene uploaded");
-    if (cam->image_width <= 0 || cam->image_height <= 0 || cam->samples_per_pixel <= 0 || cam->max_depth < 0)
-        return fail(RTK_ERR_INVALID, "rtk_render_device: bad camera dimensions");
+    if (cam->image_width <= 0 || cam->image_height <= 0 || cam->samples_per_pixel <= 0 || cam->samples_per_pixel > 32767 || cam->max_depth < 0)
+        return fail(RTK_ERR_INVALID, "rtk_render_device: bad camera dimensions (samples_per_pixel must be 1..32767)");
     if (opts->n_ranks < 1 || opts->rank < 0 || opts->rank >= opts->n_ranks) return fail(RTK_ERR_INVALID, "rtk_render_device: bad rank %d of %d", opts->rank, opts->n_ranks);
     if (opts->n_ranks > 1 && d_rgb8) return fail(RTK_ERR_INVALID, "rtk_render_device: d_rgb8 must be null when n_ranks > 1 (use rtk_tiles_unpermute)");
     if (opts->count_work && !d_counters) return fail(RTK_ERR_INVALID, "rtk_render_device: count_work needs d_counters");
@@ -593,14 +593,23 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
     tm.n_ranks = opts->n_ranks;
     tm.n_tiles_local = int32_t(rtk_tiles_per_rank(cam->image_width, cam->image_height, opts->n_ranks));
     tm.compact = opts->n_ranks > 1 ? 1 : 0;
-    // Split every pixel's samples into chunks so that no lane is stuck with a whole
-    // heavy pixel (the longest pixel would otherwise bound the kernel): about 8
-    // samples per chunk, at most 16 chunks.
-    int n_chunks = cam->samples_per_pixel / 8;
-    n_chunks = n_chunks < 1 ? 1 : (n_chunks > 16 ? 16 : n_chunks);
-    if (opts->variant & 2) n_chunks = 1;  // variant bit 1: one lane per pixel for all samples (A/B)
-    tm.chunk_spp = (cam->samples_per_pixel + n_chunks - 1) / n_chunks;
-    tm.n_chunks = (cam->samples_per_pixel + tm.chunk_spp - 1) / tm.chunk_spp;
+    // Split every pixel's samples into chunks of 4 (at most 64 chunks) so that no lane is stuck with a whole
+    // heavy pixel: a glass pixel's samples cost ~0.5 ms each, and the largest (pixel, chunk) bounds the end of
+    // the frame whatever the GPU count.  Measured on C2 (kernel time, N = 1 / one of 8 shards): 8-sample chunks
+    // 70.0 / 11.5 ms, 4-sample 72.2 / 10.2 ms, 2-sample 74.0 / 10.3 ms.  A function of spp only.
+    {
+        const int spp = cam->samples_per_pixel;
+        int n = 0;
+        tm.chunk_start[0] = 0;
+        const int ab = (opts->variant >> 3) & 3;  // tools/: chunk size A/B (0 = default 4, 1 = 8, 2 = 2, 3 = 16)
+        int size = ab == 0 ? 4 : (ab == 1 ? 8 : (ab == 2 ? 2 : 16));
+        if (opts->variant & 2) size = spp;  // variant bit 1: one lane per pixel for all samples (tests)
+        while ((spp + size - 1) / size > kMaxChunks) size++;
+        for (int s0 = size; s0 < spp; s0 += size) tm.chunk_start[++n] = int16_t(s0);
+        tm.chunk_start[++n] = int16_t(spp);
+        tm.n_chunks = n;
+        for (int k = n + 1; k <= kMaxChunks; k++) tm.chunk_start[k] = int16_t(spp);
+    }
     const size_t elem = opts->real_mode == RTK_REAL_F64 ? sizeof(double) : sizeof(float);
     const size_t need = size_t(tm.n_tiles_local) * tm.n_chunks * 192 * elem;
     if (need > ctx->partial_bytes) {
@@ -619,7 +628,7 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
     unsigned int* tile_counter = ctx->tile_counters + slot;
     unsigned char* d_cam = ctx->d_cameras + slot * kCameraStride;
     const bool allow_lds = (opts->variant & 1) == 0;  // variant bit 0: keep the program in global memory (A/B)
-    const uint32_t diag = uint32_t(opts->variant) & 0x3FF0u;  // bits 4..13: timing ablations / policy A/B used by tools/ only
+    const uint32_t diag = uint32_t(opts->variant) & 0x3F00u;  // bits 8..13: timing ablations / policy A/B used by tools/ only
     hipError_t e;
     if (opts->real_mode == RTK_REAL_F64) {
         ctx->h_cameras64[slot] = to_device_camera<double>(*cam);

@@ -67,6 +67,7 @@ inline constexpr int slots_of(uint32_t kind) {
 
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 constexpr int kMaxChain = 4;
+constexpr int kMaxChunks = 64;
 
 // Scene feature bits: which op kinds / shading paths a scene needs.  The host
 // picks the leanest kernel instantiation that covers the scene's mask.
@@ -174,10 +175,13 @@ struct TileMap {  // which tiles this launch renders and where the pixels go
     int32_t rank, n_ranks;
     int32_t compact;  // resolve output: 1 = this rank's [local_tile][3][64] buffer, 0 = the row-major image
     // Work items pulled by the persistent waves from an atomic counter: item = local_tile * n_chunks + chunk,
-    // chunk c covers samples [c * chunk_spp, min(spp, (c+1) * chunk_spp)) of each of the tile's 64 pixels.
-    // The render kernel writes one partial sum per (item, pixel) into partial[item][3][64]; the resolve
-    // kernel adds a pixel's chunks in index order (deterministic, independent of scheduling and GPU count).
-    int32_t n_chunks, chunk_spp;
+    // chunk c = samples [chunk_start[c], chunk_start[c+1]) of each of the tile's 64 pixels (all chunks of a tile
+    // are adjacent items, so a heavy tile is spread over many waves at once).  The boundaries depend on spp only,
+    // never on the number of ranks, so a pixel's partial sums -- and the image -- are the same on any GPU count.
+    // The render kernel writes one partial sum per (chunk, tile, pixel) into partial[chunk][local_tile][3][64];
+    // the resolve kernel adds a pixel's chunks in index order.
+    int32_t n_chunks;
+    int16_t chunk_start[kMaxChunks + 1];
 };
 
 // Indices into the uint64 work-counter block (same order as rtk_work_counters).

@@ -13,7 +13,7 @@ namespace rtk {
 // work-counting instantiation (always the full-feature kernel).  tile_counter is
 // a device word the persistent waves pull tile indices from (zeroed on `stream`
 // before the launch); d_cam points at the camera record in device memory.  `diag`
-// bits 16/32 are timing ablations for tools/ (wrong images, never set by the product).
+// bits 8..13 select scheduler thresholds for A/B runs from tools/ (images are unaffected).
 template <typename real>
 hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>* d_cam, const TileMap& tmap, uint32_t seed, uint32_t features, bool count,
                          bool allow_lds, uint32_t diag, void* partial, unsigned long long* counters, unsigned int* tile_counter,

@@ -827,7 +827,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
     L.s = 0;
     RTK_PROF_DECL
     bool alive = false;               // this lane currently owns a (pixel, chunk)
-    int my_item = 0, my_pix = 0, px_i = 0, px_j = 0, s_end = 0;
+    int my_slot = 0, my_pix = 0, px_i = 0, px_j = 0, s_end = 0;  // my_slot = chunk * n_tiles_local + local_tile: where the partial sum goes
 
     for (;;) {
         // ---- regeneration at pixel granularity: idle lanes take the next pixels of
@@ -850,14 +850,14 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             const int avail = 64 - refill_next;
             const int rank_in_idle = int(__builtin_amdgcn_mbcnt_hi(uint32_t(m_idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m_idle), 0u)));
             if (!alive && rank_in_idle < avail) {
-                my_item = refill_item;
                 my_pix = refill_next + rank_in_idle;
                 const int local_tile = refill_item / tmap.n_chunks, chunk = refill_item % tmap.n_chunks;
                 const int tile = local_tile * tmap.n_ranks + tmap.rank;
+                my_slot = chunk * tmap.n_tiles_local + local_tile;
                 px_i = (tile % tmap.tiles_x) * 8 + (my_pix & 7);
                 px_j = (tile / tmap.tiles_x) * 8 + (my_pix >> 3);
-                const int s_begin = chunk * tmap.chunk_spp;
-                s_end = s_begin + tmap.chunk_spp < spp ? s_begin + tmap.chunk_spp : spp;
+                const int s_begin = tmap.chunk_start[chunk];
+                s_end = tmap.chunk_start[chunk + 1];
                 if (tile < n_tiles_total && px_i < width && px_j < height && s_begin < s_end) {
                     alive = true;
                     L.sum = mk(real(0), real(0), real(0));
@@ -950,8 +950,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             int remaining;
             do {
                 if (k == OP_SPHERE) {
-                    if (diag & 32u) L.pc += 1;  // timing ablation only (tools/): skip the sphere maths
-                    else step_sphere(L, cur, cnt);
+                    step_sphere(L, cur, cnt);
                     cur = prog[L.pc];
                     k = cur.kind_payload & 15u;
                     L.kind = k;
@@ -1002,7 +1001,6 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             } while (remaining >= keep);
         } else if (pick == W_SHADE) {
             if (want == W_SHADE) {
-                if (diag & 16u) L.best_pc = kNoHit;  // timing ablation only (tools/): every segment is treated as a miss
                 const bool ended = L.depth <= 0 || shade<real, FEAT, COUNT>(L, prog, sc, mats, cam, cnt);
                 if (ended) {  // pixel_color += ray_color(...) (Camera.txt:72)
                     L.sum = L.sum + L.radiance;
@@ -1011,7 +1009,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                         begin_sample(L, cam, px_i, px_j, seed_hash, cnt);
                     } else {
                         alive = false;
-                        store_partial(partial, my_item, my_pix, L.sum);
+                        store_partial(partial, my_slot, my_pix, L.sum);
                     }
                 }
                 if (alive) {
@@ -1108,10 +1106,11 @@ __global__ __launch_bounds__(256) void rtk_resolve_kernel(const real* __restrict
     const bool inside = tile < (long long)tmap.tiles_x * tmap.tiles_y && i < width && j < height;
     V3<real> sum = mk(real(0), real(0), real(0));
     if (inside) {
-        const real* src = partial + size_t(local_tile) * tmap.n_chunks * 192 + pix;
+        const real* src = partial + size_t(local_tile) * 192 + pix;
+        const size_t chunk_stride = size_t(tmap.n_tiles_local) * 192;
         sum = mk(src[0], src[64], src[128]);
         for (int c = 1; c < tmap.n_chunks; c++) {
-            const real* q = src + size_t(c) * 192;
+            const real* q = src + size_t(c) * chunk_stride;
             sum = sum + mk(q[0], q[64], q[128]);
         }
         sum = scale(samples_scale, sum);

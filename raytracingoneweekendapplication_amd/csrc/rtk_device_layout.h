@@ -82,6 +82,9 @@ enum Feature : uint32_t {
 };
 constexpr uint32_t kFeatLean = 0;                       // spheres + lambertian/metal/dielectric with solid colours
 constexpr uint32_t kFeatAll = 0x7F;
+// Two common subsets get their own instantiation (fewer live registers than the full kernel):
+constexpr uint32_t kFeatQuadBox = F_QUAD | F_XFORM | F_EXOTIC_MAT;  // quads, box() instances, area lights (the Cornell box)
+constexpr uint32_t kFeatMesh = F_TRI | F_EXOTIC_MAT;                // triangle meshes + spheres + emissive spheres
 
 template <typename real>
 struct alignas(16) SphereRec {  // sphere.h:60-64

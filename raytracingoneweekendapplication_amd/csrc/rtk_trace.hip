@@ -781,7 +781,7 @@ RTK_DEV void store_partial(real* __restrict__ partial, int item, int pix, V3<rea
 // needs more registers than that (it spilled ~560 B/lane at 168), so it is bounded at 512 threads
 // (2 waves per SIMD, 256 VGPRs).
 template <typename real, uint32_t FEAT>
-constexpr int max_threads() { return (sizeof(real) == 8 && FEAT != kFeatLean) ? 512 : 768; }
+constexpr int max_threads() { return (sizeof(real) == 8 && FEAT == kFeatAll) ? 512 : 768; }
 
 template <typename real, uint32_t FEAT, bool COUNT, bool IN_LDS>
 __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel(SceneView<real> sc, const CameraRec<real>* __restrict__ cam_ptr, TileMap tmap, uint32_t seed,
@@ -1238,6 +1238,12 @@ hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>* cam, 
     if (features == kFeatLean)
         return lds ? launch_one<real, kFeatLean, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream)
                    : launch_one<real, kFeatLean, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream);
+    if ((features & ~kFeatQuadBox) == 0)
+        return lds ? launch_one<real, kFeatQuadBox, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream)
+                   : launch_one<real, kFeatQuadBox, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream);
+    if ((features & ~kFeatMesh) == 0)
+        return lds ? launch_one<real, kFeatMesh, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream)
+                   : launch_one<real, kFeatMesh, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream);
     return lds ? launch_one<real, kFeatAll, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream)
                : launch_one<real, kFeatAll, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream);
 }
@@ -1284,13 +1290,10 @@ template hipError_t launch_unpermute<double>(const void*, int, int, int, long lo
 template hipError_t launch_unpermute<float>(const void*, int, int, int, long long, void*, uint8_t*, hipStream_t);
 
 const char* render_kernel_name(bool f64, uint32_t features, bool count, bool lds) {
-    if (count) return f64 ? "rtk_render_kernel<double, 127u, true, false>" : "rtk_render_kernel<float, 127u, true, false>";
-    if (features == kFeatLean) {
-        if (lds) return f64 ? "rtk_render_kernel<double, 0u, false, true>" : "rtk_render_kernel<float, 0u, false, true>";
-        return f64 ? "rtk_render_kernel<double, 0u, false, false>" : "rtk_render_kernel<float, 0u, false, false>";
-    }
-    if (lds) return f64 ? "rtk_render_kernel<double, 127u, false, true>" : "rtk_render_kernel<float, 127u, false, true>";
-    return f64 ? "rtk_render_kernel<double, 127u, false, false>" : "rtk_render_kernel<float, 127u, false, false>";
+    static thread_local char name[96];
+    const uint32_t feat = count ? kFeatAll : (features == kFeatLean ? kFeatLean : ((features & ~kFeatQuadBox) == 0 ? kFeatQuadBox : ((features & ~kFeatMesh) == 0 ? kFeatMesh : kFeatAll)));
+    snprintf(name, sizeof name, "rtk_render_kernel<%s, %uu, %s, %s>", f64 ? "double" : "float", feat, count ? "true" : "false", (lds && !count) ? "true" : "false");
+    return name;
 }
 
 }  // namespace rtk

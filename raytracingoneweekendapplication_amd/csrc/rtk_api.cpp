@@ -333,22 +333,8 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
             default: break;
         }
     }
-    std::vector<SphereRec<real>> spheres(sc.n_spheres);
-    for (int32_t i = 0; i < sc.n_spheres; i++) {
-        const rtk_sphere& s = sc.spheres[i];
-        const bool moving = s.center_dir.x != 0 || s.center_dir.y != 0 || s.center_dir.z != 0;
-        spheres[i] = SphereRec<real>{real(s.center0.x), real(s.center0.y), real(s.center0.z), real(s.radius), real(s.center_dir.x), real(s.center_dir.y),
-                                     real(s.center_dir.z), s.material, moving ? 1 : 0};
-    }
-    std::vector<QuadRec<real>> quads(sc.n_quads);
-    for (int32_t i = 0; i < sc.n_quads; i++) {
-        const rtk_quad& q = sc.quads[i];
-        QuadRec<real>& r = quads[i];
-        store3(r.Q, q.Q); store3(r.u, q.u); store3(r.v, q.v); store3(r.w, q.w); store3(r.n, q.normal);
-        r.D = real(q.D);
-        r.material = q.material;
-        r._pad = 0;
-    }
+    // Sphere, quad and medium records live entirely in their program slots; only triangles keep a side record
+    // (normal + UVs for the deferred hit record).
     std::vector<TriRec<real>> tris(sc.n_triangles);
     for (int32_t i = 0; i < sc.n_triangles; i++) {
         const rtk_triangle& t = sc.triangles[i];
@@ -362,8 +348,6 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
         r.material = t.material;
         r._pad = 0;
     }
-    std::vector<MediumRec<real>> media(sc.n_media);
-    for (int32_t i = 0; i < sc.n_media; i++) media[i] = MediumRec<real>{real(sc.media[i].neg_inv_density), sc.media[i].material, 0};
 
     std::vector<MaterialRec<real>> mats(sc.n_materials);
     for (int32_t i = 0; i < sc.n_materials; i++) {
@@ -432,10 +416,7 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
     }
     int rc;
     if ((rc = out.upload(slots, &out.view.program)) != RTK_OK) return rc;
-    if ((rc = out.upload(spheres, &out.view.spheres)) != RTK_OK) return rc;
-    if ((rc = out.upload(quads, &out.view.quads)) != RTK_OK) return rc;
     if ((rc = out.upload(tris, &out.view.tris)) != RTK_OK) return rc;
-    if ((rc = out.upload(media, &out.view.media)) != RTK_OK) return rc;
     if ((rc = out.upload(mats, &out.view.materials)) != RTK_OK) return rc;
     if ((rc = out.upload(texs, &out.view.textures)) != RTK_OK) return rc;
     if ((rc = out.upload(images, &out.view.images)) != RTK_OK) return rc;

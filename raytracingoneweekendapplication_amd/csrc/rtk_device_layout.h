@@ -87,29 +87,9 @@ constexpr uint32_t kFeatQuadBox = F_QUAD | F_XFORM | F_EXOTIC_MAT;  // quads, bo
 constexpr uint32_t kFeatMesh = F_TRI | F_EXOTIC_MAT;                // triangle meshes + spheres + emissive spheres
 
 template <typename real>
-struct alignas(16) SphereRec {  // sphere.h:60-64
-    real cx, cy, cz, radius;
-    real dx, dy, dz;            // center motion (center2 - center1); 0 for a static sphere
-    int32_t material;
-    int32_t moving;             // dx,dy,dz not all zero
-};
-
-template <typename real>
-struct alignas(16) QuadRec {  // quad.h:76-83
-    real Q[3], u[3], v[3], w[3], n[3], D;
-    int32_t material, _pad;
-};
-
-template <typename real>
 struct alignas(16) TriRec {  // triangle.h:124-143; e1 = p1-p0, e2 = p2-p0 are what hit() recomputes per call
     real p0[3], e1[3], e2[3], n[3];
     float uv0[2], uv1[2], uv2[2];
-    int32_t material, _pad;
-};
-
-template <typename real>
-struct alignas(16) MediumRec {  // constant_medium.h:57-59
-    real neg_inv_density;
     int32_t material, _pad;
 };
 
@@ -159,10 +139,7 @@ struct CameraRec {  // Camera.txt:122-131
 template <typename real>
 struct SceneView {  // device pointers, passed to the kernel by value
     const Slot<real>* program;  // the traversal program (copied to LDS by each workgroup when it fits)
-    const SphereRec<real>* spheres;
-    const QuadRec<real>* quads;
     const TriRec<real>* tris;
-    const MediumRec<real>* media;
     const MaterialRec<real>* materials;
     const TextureRec<real>* textures;
     const ImageRec* images;

@@ -818,6 +818,10 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
     // `refill_next` on have not been given to a lane yet.
     const int n_items = tmap.n_tiles_local * tmap.n_chunks;
     int refill_item = 0, refill_next = 64;
+    // The index of the NEXT work item is fetched one item ahead: the returning atomic is issued when an item is
+    // taken and only waited for when its 64 pixels have been handed out, so its ~2 us round trip never stalls the wave.
+    unsigned int prefetched_item = 0;
+    if (lane == 0) prefetched_item = atomicAdd(tile_counter, 1u);
     bool exhausted = false;
 
     Lane<real> L;
@@ -837,15 +841,14 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
         unsigned long long m_idle = __ballot(!alive);
         while (m_idle != 0ull && !exhausted) {
             if (refill_next >= 64) {
-                unsigned int fetched = 0;
-                if (lane == 0) fetched = atomicAdd(tile_counter, 1u);
-                const int t = int(__builtin_amdgcn_readfirstlane(fetched));
+                const int t = int(__builtin_amdgcn_readfirstlane(prefetched_item));
                 if (t >= n_items) {
                     exhausted = true;
                     break;
                 }
                 refill_item = t;
                 refill_next = 0;
+                if (lane == 0) prefetched_item = atomicAdd(tile_counter, 1u);
             }
             const int avail = 64 - refill_next;
             const int rank_in_idle = int(__builtin_amdgcn_mbcnt_hi(uint32_t(m_idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m_idle), 0u)));

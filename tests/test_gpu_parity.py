@@ -112,6 +112,18 @@ def test_ragged_sizes_and_degenerate_settings(rt, orc, renderer, scenes, shape):
     assert rmse(gpu, ref) < F64_RMSE_BOUND and np.array_equal(gpu8, ref8) and counters == ocnt
 
 
+def test_max_depth_zero_renders_black_like_the_reference(rt, orc, renderer, scenes):
+    """ray_color returns (0,0,0) before any hit test when depth <= 0 (Camera.txt:205-206)."""
+    scene = scenes("three_spheres")
+    cam = scene.camera(24, 16, 3, 1)
+    cam.max_depth = 0
+    renderer.upload(scene)
+    gpu, gpu8, counters = renderer.render_host(cam, count=True)
+    ref, ref8, ocnt = orc.render(scene.desc_ptr, cam, RENDER_SEED, 2)
+    assert not gpu.any() and not ref.any() and not gpu8.any()
+    assert counters == ocnt and counters["segments"] == 0 and counters["samples"] == 24 * 16 * 3
+
+
 def test_seed_and_determinism(rt, renderer, scenes):
     scene = scenes("cornell_smoke")
     cam = scene.camera(48, 48, 8, 10)
@@ -123,8 +135,8 @@ def test_seed_and_determinism(rt, renderer, scenes):
     assert not np.array_equal(a, c)
 
 
-@pytest.mark.parametrize("n_ranks", [2, 3, 8])
-def test_tile_sharding_is_bit_identical_to_one_gpu(rt, renderer, scenes, n_ranks):
+@pytest.mark.parametrize("n_ranks,real", [(2, "f64"), (3, "f64"), (8, "f64"), (4, "f32")])
+def test_tile_sharding_is_bit_identical_to_one_gpu(rt, renderer, scenes, n_ranks, real):
     """P4 of SURVEY.md 8(d): the image must not depend on the GPU count.  All ranks run on this one
     device into their compact buffers; the gather is emulated by stacking (the real one is
     torch.distributed.gather over RCCL, covered on CPU/gloo by test_distributed_cpu.py)."""
@@ -134,23 +146,25 @@ def test_tile_sharding_is_bit_identical_to_one_gpu(rt, renderer, scenes, n_ranks
     scene = scenes("book1_final")
     cam = scene.camera(100, 60, 8, 50)   # 13 x 8 = 104 tiles: not a multiple of 3 or 8 -> padded last tiles
     renderer.upload(scene)
-    whole, whole8, _ = renderer.render_host(cam)
+    mode = rt.RTK_REAL_F64 if real == "f64" else rt.RTK_REAL_F32
+    dtype = torch.float64 if real == "f64" else torch.float32
+    whole, whole8, _ = renderer.render_host(cam, real_mode=mode)
     dev = torch.device("cuda", 0)
     tpr = tiling.tiles_per_rank(100, 60, n_ranks)
     parts = []
     for rank in range(n_ranks):
-        buf = torch.full((tpr, 3, 64), float("nan"), dtype=torch.float64, device=dev)
-        renderer.render_device(cam, buf.data_ptr(), 0, rank=rank, n_ranks=n_ranks)
+        buf = torch.full((tpr, 3, 64), float("nan"), dtype=dtype, device=dev)
+        renderer.render_device(cam, buf.data_ptr(), 0, real_mode=mode, rank=rank, n_ranks=n_ranks)
         parts.append(buf)
     gathered = torch.stack(parts).contiguous()
-    image = torch.empty((60, 100, 3), dtype=torch.float64, device=dev)
+    image = torch.empty((60, 100, 3), dtype=dtype, device=dev)
     rgb8 = torch.empty((60, 100, 3), dtype=torch.uint8, device=dev)
-    renderer.unpermute(100, 60, n_ranks, rt.RTK_REAL_F64, gathered.data_ptr(), image.data_ptr(), rgb8.data_ptr())
+    renderer.unpermute(100, 60, n_ranks, mode, gathered.data_ptr(), image.data_ptr(), rgb8.data_ptr())
     torch.cuda.synchronize()
-    assert np.array_equal(image.cpu().numpy(), whole)
+    assert np.array_equal(image.cpu().numpy().astype(np.float64), whole)
     assert np.array_equal(rgb8.cpu().numpy(), whole8)
     # and the device layout is the one the CPU/gloo path assumes
-    assert np.array_equal(tiling.image_from_gathered(gathered.cpu().numpy(), 100, 60, n_ranks), whole)
+    assert np.array_equal(tiling.image_from_gathered(gathered.cpu().numpy(), 100, 60, n_ranks).astype(np.float64), whole)
 
 
 def test_error_behaviour(rt, renderer, scenes, tmp_path):

@@ -309,14 +309,21 @@ RTK_DEV bool regular_direction(V3<real> inv) {
            rt_fabs(inv.z) < inf;
 }
 
+// The ray the records are tested against: the object-space ray when the scene has instance transforms, else the
+// world-space ray itself (no second copy is kept in registers).
+template <bool XF, typename real> RTK_DEV const V3<real>& ray_o(const Lane<real>& L) { if constexpr (XF) return L.o; else return L.ro; }
+template <bool XF, typename real> RTK_DEV const V3<real>& ray_d(const Lane<real>& L) { if constexpr (XF) return L.d; else return L.rd; }
+
 // world.hit(r, interval(0.001, inf), rec) (Camera.txt:211) starts here.
-template <typename real, bool COUNT>
+template <bool XF, typename real, bool COUNT>
 RTK_DEV void begin_segment(Lane<real>& L, Counters<COUNT>& cnt) {
     cnt.inc(C_SEGMENTS);
-    L.o = L.ro;
-    L.d = L.rd;
-    L.inv = mk(real(1) / L.d.x, real(1) / L.d.y, real(1) / L.d.z);
-    L.a = length_squared(L.d);
+    if constexpr (XF) {
+        L.o = L.ro;
+        L.d = L.rd;
+    }
+    L.inv = mk(real(1) / L.rd.x, real(1) / L.rd.y, real(1) / L.rd.z);
+    L.a = length_squared(L.rd);
     L.regular = regular_direction(L.inv);
     L.tmin = real(0.001);
     L.best_t = real_inf<real>();
@@ -325,19 +332,19 @@ RTK_DEV void begin_segment(Lane<real>& L, Counters<COUNT>& cnt) {
 }
 
 // bvh_node::hit's box test (bvh.h:65): on a miss skip the whole subtree.
-template <bool EXACT_NAN, typename real, bool COUNT>
+template <bool EXACT_NAN, bool XF, typename real, bool COUNT>
 RTK_DEV void step_box(Lane<real>& L, const Slot<real>& rec, Counters<COUNT>& cnt) {
     cnt.inc(C_BOX);
-    const bool hit = slab_test<EXACT_NAN>(rec, L.o, L.inv, L.tmin, L.best_t);
+    const bool hit = slab_test<EXACT_NAN>(rec, ray_o<XF>(L), L.inv, L.tmin, L.best_t);
     L.pc = hit ? L.pc + 1 : rec.aux;
 }
 
 // sphere::hit of a stationary sphere.
-template <typename real, bool COUNT>
+template <bool XF, typename real, bool COUNT>
 RTK_DEV void step_sphere(Lane<real>& L, const Slot<real>& rec, Counters<COUNT>& cnt) {
     cnt.inc(C_SPHERE);
     real r;
-    if (sphere_root(mk(rec.v[0], rec.v[1], rec.v[2]), rec.v[3], L.o, L.d, L.a, L.tmin, L.best_t, r)) {
+    if (sphere_root(mk(rec.v[0], rec.v[1], rec.v[2]), rec.v[3], ray_o<XF>(L), ray_d<XF>(L), L.a, L.tmin, L.best_t, r)) {
         L.best_t = r;
         L.best_pc = L.pc;
     }
@@ -348,13 +355,14 @@ RTK_DEV void step_sphere(Lane<real>& L, const Slot<real>& rec, Counters<COUNT>& 
 // medium ops).  `rec` points at the record in the program (LDS or global).
 template <typename real, uint32_t FEAT, bool COUNT>
 RTK_DEV void step_other(Lane<real>& L, const Slot<real>* __restrict__ rec, const SceneView<real>& sc, Counters<COUNT>& cnt) {
+    constexpr bool XF = (FEAT & F_XFORM) != 0;
     const uint32_t kp = rec->kind_payload;
     const uint32_t kind = kp & 15u;
     if (kind == OP_SPHERE_MOVING) {
         cnt.inc(C_SPHERE);
         real r;
         V3<real> cc = mk(rec->v[0], rec->v[1], rec->v[2]) + scale(L.tm, mk(rec[1].v[0], rec[1].v[1], rec[1].v[2]));
-        if (sphere_root(cc, rec->v[3], L.o, L.d, L.a, L.tmin, L.best_t, r)) {
+        if (sphere_root(cc, rec->v[3], ray_o<XF>(L), ray_d<XF>(L), L.a, L.tmin, L.best_t, r)) {
             L.best_t = r;
             L.best_pc = L.pc;
         }
@@ -362,7 +370,7 @@ RTK_DEV void step_other(Lane<real>& L, const Slot<real>* __restrict__ rec, const
     } else if ((FEAT & F_QUAD) && kind == OP_QUAD) {
         cnt.inc(C_QUAD);
         real t, al, be;
-        if (quad_test(rec, L.o, L.d, L.tmin, L.best_t, t, al, be)) {
+        if (quad_test(rec, ray_o<XF>(L), ray_d<XF>(L), L.tmin, L.best_t, t, al, be)) {
             L.best_t = t;
             L.best_pc = L.pc;
         }
@@ -371,7 +379,7 @@ RTK_DEV void step_other(Lane<real>& L, const Slot<real>* __restrict__ rec, const
         cnt.inc(C_TRI);
         real t;
         float fa, fb, fg;
-        if (tri_test(rec, L.o, L.d, L.tmin, L.best_t, t, fa, fb, fg)) {
+        if (tri_test(rec, ray_o<XF>(L), ray_d<XF>(L), L.tmin, L.best_t, t, fa, fb, fg)) {
             L.best_t = t;
             L.best_pc = L.pc;
         }
@@ -777,11 +785,15 @@ RTK_DEV void store_partial(real* __restrict__ partial, int item, int pix, V3<rea
     base[128] = sum.z;
 }
 
-// Workgroup-size bound: 768 threads = 3 waves per SIMD = up to 168 VGPRs.  The full-feature f64 kernel
-// needs more registers than that (it spilled ~560 B/lane at 168), so it is bounded at 512 threads
-// (2 waves per SIMD, 256 VGPRs).
+// Workgroup-size bound = register budget: 1024 threads -> 4 waves per SIMD, 128 VGPRs; 768 -> 3 waves, 168 VGPRs;
+// 512 -> 2 waves, 256 VGPRs.  Measured on C2 (lean f64 kernel): 2 waves 93.8 ms, 3 waves 73.5 ms, 4 waves 68.5 ms
+// per frame (the 4-wave build spills a few values in the shade path).  The full-feature f64 kernel needs far more
+// registers (it spilled ~560 B/lane at 168) and stays at 2 waves per SIMD.
 template <typename real, uint32_t FEAT>
-constexpr int max_threads() { return (sizeof(real) == 8 && FEAT == kFeatAll) ? 512 : 768; }
+constexpr int max_threads() {
+    if (sizeof(real) == 8) return FEAT == kFeatAll ? 512 : (FEAT == kFeatLean ? 1024 : 768);
+    return 768;
+}
 
 template <typename real, uint32_t FEAT, bool COUNT, bool IN_LDS>
 __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel(SceneView<real> sc, const CameraRec<real>* __restrict__ cam_ptr, TileMap tmap, uint32_t seed,
@@ -866,7 +878,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                     L.sum = mk(real(0), real(0), real(0));
                     L.s = s_begin;
                     begin_sample(L, cam, px_i, px_j, seed_hash, cnt);
-                    if (L.depth > 0) begin_segment(L, cnt);
+                    if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0>(L, cnt);
                     else L.pc = end_pc;  // max_depth == 0: ray_color returns black at once (Camera.txt:205-206)
                     L.kind = prog[L.pc].kind_payload & 15u;
                 }
@@ -924,7 +936,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             if (__ballot(want == W_BOX && !L.regular) == 0ull) {
                 do {
                     if (k == OP_BOX) {
-                        step_box<false>(L, cur, cnt);
+                        step_box<false, (FEAT & F_XFORM) != 0>(L, cur, cnt);
                         cur = prog[L.pc];
                         k = cur.kind_payload & 15u;
                         L.kind = k;
@@ -935,7 +947,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             } else {  // some lane has a ray with a zero/infinite direction component: literal NaN handling for this round
                 do {
                     if (k == OP_BOX) {
-                        step_box<true>(L, cur, cnt);
+                        step_box<true, (FEAT & F_XFORM) != 0>(L, cur, cnt);
                         cur = prog[L.pc];
                         k = cur.kind_payload & 15u;
                         L.kind = k;
@@ -953,7 +965,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             int remaining;
             do {
                 if (k == OP_SPHERE) {
-                    step_sphere(L, cur, cnt);
+                    step_sphere<(FEAT & F_XFORM) != 0>(L, cur, cnt);
                     cur = prog[L.pc];
                     k = cur.kind_payload & 15u;
                     L.kind = k;
@@ -970,7 +982,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                 if (k == OP_QUAD) {
                     cnt.inc(C_QUAD);
                     real t, al, be;
-                    if (quad_test(prog + L.pc, L.o, L.d, L.tmin, L.best_t, t, al, be)) {
+                    if (quad_test(prog + L.pc, ray_o<(FEAT & F_XFORM) != 0>(L), ray_d<(FEAT & F_XFORM) != 0>(L), L.tmin, L.best_t, t, al, be)) {
                         L.best_t = t;
                         L.best_pc = L.pc;
                     }
@@ -991,7 +1003,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                     cnt.inc(C_TRI);
                     real t;
                     float fa, fb, fg;
-                    if (tri_test(prog + L.pc, L.o, L.d, L.tmin, L.best_t, t, fa, fb, fg)) {
+                    if (tri_test(prog + L.pc, ray_o<(FEAT & F_XFORM) != 0>(L), ray_d<(FEAT & F_XFORM) != 0>(L), L.tmin, L.best_t, t, fa, fb, fg)) {
                         L.best_t = t;
                         L.best_pc = L.pc;
                     }
@@ -1016,7 +1028,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                     }
                 }
                 if (alive) {
-                    if (L.depth > 0) begin_segment(L, cnt);
+                    if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0>(L, cnt);
                     else L.pc = end_pc;
                     L.kind = prog[L.pc].kind_payload & 15u;
                 }
@@ -1059,7 +1071,7 @@ __global__ __launch_bounds__(256) void rtk_debug_hit_kernel(SceneView<real> sc, 
     L.rng = pcg_hash(keys[gid * 3 + 1] + pcg_hash(keys[gid * 3 + 2] + pcg_hash(keys[gid * 3])));
     L.sv_tmin = L.sv_best_t = L.rec1_t = real(0);
     L.sv_best_pc = kNoHit;
-    begin_segment(L, cnt);
+    begin_segment<true>(L, cnt);
     L.tmin = real(r[7]);
     L.best_t = real(r[8]);
     const Slot<real>* prog = sc.program;
@@ -1068,10 +1080,10 @@ __global__ __launch_bounds__(256) void rtk_debug_hit_kernel(SceneView<real> sc, 
         const uint32_t kind = rec->kind_payload & 15u;
         if (kind == OP_END) break;
         if (kind == OP_BOX) {
-            if (L.regular) step_box<false>(L, *rec, cnt);
-            else step_box<true>(L, *rec, cnt);
+            if (L.regular) step_box<false, true>(L, *rec, cnt);
+            else step_box<true, true>(L, *rec, cnt);
         } else if (kind == OP_SPHERE) {
-            step_sphere(L, *rec, cnt);
+            step_sphere<true>(L, *rec, cnt);
         } else {
             step_other<real, kFeatAll, true>(L, rec, sc, cnt);
         }

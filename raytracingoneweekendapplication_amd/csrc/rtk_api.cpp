@@ -469,6 +469,13 @@ struct rtk_ctx {
     // successive launches (they are ordered on the caller's stream).
     void* d_partial = nullptr;
     size_t partial_bytes = 0;
+    // Longest-processing-time-first tile order, learned from the previous frame of the same shape: the render
+    // kernel accumulates a per-tile cost, rtk_tile_order_kernel turns it into the hand-out order of the next launch.
+    unsigned int* d_tile_cost = nullptr;
+    int32_t* d_tile_order = nullptr;
+    int order_capacity = 0;
+    bool order_valid = false;
+    int order_shape[5] = {0, 0, 0, 0, 0};  // width, height, rank, n_ranks, tiles: what the stored order was measured on
     std::vector<CameraRec<double>> h_cameras64;
     std::vector<CameraRec<float>> h_cameras32;
 };
@@ -518,6 +525,8 @@ int rtk_destroy(rtk_ctx* ctx) {
     if (ctx->tile_counters) (void)hipFree(ctx->tile_counters);
     if (ctx->d_cameras) (void)hipFree(ctx->d_cameras);
     if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+    if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
+    if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
     delete ctx;
     return RTK_OK;
 }
@@ -543,6 +552,7 @@ int rtk_scene_upload(rtk_ctx* ctx, const rtk_scene_desc* scene) {
 
     RTK_HIP(hipSetDevice(ctx->device));
     ctx->has_scene = false;
+    ctx->order_valid = false;  // a new scene: tile costs measured on the old one mean nothing
     if ((rc = build_device_scene<double>(*scene, prog, ctx->scene64)) != RTK_OK) return rc;
     if ((rc = build_device_scene<float>(*scene, prog, ctx->scene32)) != RTK_OK) return rc;
     ctx->features = prog.features;
@@ -605,6 +615,26 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
     }
     hipStream_t stream = static_cast<hipStream_t>(opts->stream);
     auto* counters = reinterpret_cast<unsigned long long*>(d_counters);
+    // tile order / cost buffers for this shape
+    const int shape[5] = {cam->image_width, cam->image_height, opts->rank, opts->n_ranks, tm.n_tiles_local};
+    if (tm.n_tiles_local > ctx->order_capacity) {
+        if (ctx->d_tile_cost) {
+            RTK_HIP(hipDeviceSynchronize());
+            RTK_HIP(hipFree(ctx->d_tile_cost));
+            RTK_HIP(hipFree(ctx->d_tile_order));
+            ctx->d_tile_cost = nullptr;
+            ctx->d_tile_order = nullptr;
+        }
+        RTK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_tile_cost), size_t(tm.n_tiles_local) * sizeof(unsigned int)));
+        RTK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_tile_order), size_t(tm.n_tiles_local) * sizeof(int32_t)));
+        ctx->order_capacity = tm.n_tiles_local;
+        ctx->order_valid = false;
+    }
+    if (std::memcmp(shape, ctx->order_shape, sizeof shape) != 0) ctx->order_valid = false;
+    const bool learn = (opts->variant & 4) == 0;  // variant bit 2: fixed row-major tile order (A/B, tests)
+    if (!ctx->order_valid && learn) RTK_HIP(hipMemsetAsync(ctx->d_tile_cost, 0, size_t(tm.n_tiles_local) * sizeof(unsigned int), stream));
+    const int32_t* tile_order = (ctx->order_valid && learn) ? ctx->d_tile_order : nullptr;
+    unsigned int* tile_cost = learn ? ctx->d_tile_cost : nullptr;
     const unsigned int slot = ctx->next_counter++ % kCounterRing;
     unsigned int* tile_counter = ctx->tile_counters + slot;
     unsigned char* d_cam = ctx->d_cameras + slot * kCameraStride;
@@ -615,14 +645,19 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
         ctx->h_cameras64[slot] = to_device_camera<double>(*cam);
         RTK_HIP(hipMemcpyAsync(d_cam, &ctx->h_cameras64[slot], sizeof(CameraRec<double>), hipMemcpyHostToDevice, stream));
         e = launch_render<double>(ctx->scene64.view, reinterpret_cast<const CameraRec<double>*>(d_cam), tm, opts->seed, ctx->features,
-                                  opts->count_work != 0, allow_lds, diag, ctx->d_partial, counters, tile_counter, stream);
+                                  opts->count_work != 0, allow_lds, diag, ctx->d_partial, counters, tile_counter, tile_order, tile_cost, stream);
         if (e == hipSuccess) e = launch_resolve<double>(ctx->d_partial, tm, cam->image_width, cam->image_height, cam->pixel_samples_scale, d_linear, d_rgb8, stream);
     } else {
         ctx->h_cameras32[slot] = to_device_camera<float>(*cam);
         RTK_HIP(hipMemcpyAsync(d_cam, &ctx->h_cameras32[slot], sizeof(CameraRec<float>), hipMemcpyHostToDevice, stream));
         e = launch_render<float>(ctx->scene32.view, reinterpret_cast<const CameraRec<float>*>(d_cam), tm, opts->seed, ctx->features,
-                                 opts->count_work != 0, allow_lds, diag, ctx->d_partial, counters, tile_counter, stream);
+                                 opts->count_work != 0, allow_lds, diag, ctx->d_partial, counters, tile_counter, tile_order, tile_cost, stream);
         if (e == hipSuccess) e = launch_resolve<float>(ctx->d_partial, tm, cam->image_width, cam->image_height, cam->pixel_samples_scale, d_linear, d_rgb8, stream);
+    }
+    if (e == hipSuccess && learn) {  // this frame's costs become the next frame's hand-out order
+        e = launch_tile_order(ctx->d_tile_cost, tm.n_tiles_local, ctx->d_tile_order, stream);
+        ctx->order_valid = e == hipSuccess;
+        std::memcpy(ctx->order_shape, shape, sizeof shape);
     }
     if (e != hipSuccess) return fail(RTK_ERR_HIP, "render kernel launch failed: %s", hipGetErrorString(e));
     return RTK_OK;

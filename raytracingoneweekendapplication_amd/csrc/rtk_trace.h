@@ -17,7 +17,10 @@ namespace rtk {
 template <typename real>
 hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>* d_cam, const TileMap& tmap, uint32_t seed, uint32_t features, bool count,
                          bool allow_lds, uint32_t diag, void* partial, unsigned long long* counters, unsigned int* tile_counter,
-                         hipStream_t stream);
+                         const int32_t* tile_order, unsigned int* tile_cost, hipStream_t stream);
+
+// cost[n] (segments per local tile, measured by the frame just rendered) -> order[n], most expensive first; clears cost.
+hipError_t launch_tile_order(unsigned int* cost, int n, int32_t* order, hipStream_t stream);
 
 // Partial sums [item][3][64] -> the row-major image (+ bytes) or this rank's compact tile buffer.
 template <typename real>

@@ -299,6 +299,7 @@ struct Lane {
     V3<real> throughput, radiance, sum;
     uint32_t pc, kind, best_pc, sv_best_pc, rng;  // kind = record kind at pc (kept in a register so the vote needs no LDS read)
     int depth, s;
+    uint32_t segs;           // segments traced for the current (pixel, chunk): the tile-cost estimate
     bool regular;            // 1/d finite and non-zero on all three axes: slab tests cannot produce NaNs
 };
 
@@ -318,6 +319,7 @@ template <bool XF, typename real> RTK_DEV const V3<real>& ray_d(const Lane<real>
 template <bool XF, typename real, bool COUNT>
 RTK_DEV void begin_segment(Lane<real>& L, Counters<COUNT>& cnt) {
     cnt.inc(C_SEGMENTS);
+    L.segs += 1;
     if constexpr (XF) {
         L.o = L.ro;
         L.d = L.rd;
@@ -798,7 +800,8 @@ constexpr int max_threads() {
 template <typename real, uint32_t FEAT, bool COUNT, bool IN_LDS>
 __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel(SceneView<real> sc, const CameraRec<real>* __restrict__ cam_ptr, TileMap tmap, uint32_t seed,
                                                           real* __restrict__ partial, unsigned long long* __restrict__ counters,
-                                                          unsigned int* __restrict__ tile_counter, uint32_t diag) {
+                                                          unsigned int* __restrict__ tile_counter, const int32_t* __restrict__ tile_order,
+                                                          unsigned int* __restrict__ tile_cost, uint32_t diag) {
     extern __shared__ __align__(16) unsigned char lds_program[];
     const Slot<real>* prog = sc.program;
     const MaterialRec<real>* mats = sc.materials;
@@ -843,7 +846,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
     L.s = 0;
     RTK_PROF_DECL
     bool alive = false;               // this lane currently owns a (pixel, chunk)
-    int my_slot = 0, my_pix = 0, px_i = 0, px_j = 0, s_end = 0;  // my_slot = chunk * n_tiles_local + local_tile: where the partial sum goes
+    int my_slot = 0, my_pix = 0, px_i = 0, px_j = 0, s_end = 0, cost_tile = -1;  // my_slot = chunk * n_tiles_local + local_tile: where the partial sum goes
 
     for (;;) {
         // ---- regeneration at pixel granularity: idle lanes take the next pixels of
@@ -866,7 +869,10 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             const int rank_in_idle = int(__builtin_amdgcn_mbcnt_hi(uint32_t(m_idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m_idle), 0u)));
             if (!alive && rank_in_idle < avail) {
                 my_pix = refill_next + rank_in_idle;
-                const int local_tile = refill_item / tmap.n_chunks, chunk = refill_item % tmap.n_chunks;
+                // Items are handed out in `tile_order` when the host has one (most expensive tiles of the previous
+                // frame first); which wave renders a tile, and when, never changes a pixel's value.
+                const int position = refill_item / tmap.n_chunks, chunk = refill_item % tmap.n_chunks;
+                const int local_tile = tile_order ? tile_order[position] : position;
                 const int tile = local_tile * tmap.n_ranks + tmap.rank;
                 my_slot = chunk * tmap.n_tiles_local + local_tile;
                 px_i = (tile % tmap.tiles_x) * 8 + (my_pix & 7);
@@ -877,6 +883,8 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                     alive = true;
                     L.sum = mk(real(0), real(0), real(0));
                     L.s = s_begin;
+                    L.segs = 0;
+                    cost_tile = chunk == 0 ? local_tile : -1;  // chunk 0 of every pixel reports the tile's cost
                     begin_sample(L, cam, px_i, px_j, seed_hash, cnt);
                     if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0>(L, cnt);
                     else L.pc = end_pc;  // max_depth == 0: ray_color returns black at once (Camera.txt:205-206)
@@ -1025,6 +1033,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                     } else {
                         alive = false;
                         store_partial(partial, my_slot, my_pix, L.sum);
+                        if (tile_cost && cost_tile >= 0) atomicAdd(&tile_cost[cost_tile], L.segs);  // no return value: fire and forget
                     }
                 }
                 if (alive) {
@@ -1103,6 +1112,47 @@ __global__ __launch_bounds__(256) void rtk_debug_hit_kernel(SceneView<real> sc, 
         o[11] = double(sf.material);
     }
     draws[gid] = cnt.c[C_RNG];
+}
+
+// Tile order for the NEXT frame: local tiles sorted by the cost measured in this frame, most expensive first
+// (64 buckets on a scale relative to the maximum: a counting sort, one workgroup).  A frame cannot end before its
+// slowest sample -- a 50-bounce path inside a glass sphere is one sequential ~2-3 ms chain on one lane -- so the
+// expensive tiles must START early; otherwise every GPU idles ~2.5 ms at the end of its share of the frame.
+// Clears the cost array for the next measurement.
+__global__ __launch_bounds__(1024) void rtk_tile_order_kernel(unsigned int* __restrict__ cost, int n, int32_t* __restrict__ order) {
+    __shared__ unsigned int s_max;
+    __shared__ unsigned int s_count[64], s_base[64];
+    const int tid = threadIdx.x;
+    if (tid == 0) s_max = 0;
+    if (tid < 64) s_count[tid] = 0;
+    __syncthreads();
+    unsigned int local_max = 0;
+    for (int k = tid; k < n; k += 1024) local_max = cost[k] > local_max ? cost[k] : local_max;
+    atomicMax(&s_max, local_max);
+    __syncthreads();
+    const unsigned long long top = (unsigned long long)s_max + 1ull;
+    for (int k = tid; k < n; k += 1024) atomicAdd(&s_count[63 - int((unsigned long long)cost[k] * 64ull / top)], 1u);  // bucket 0 = most expensive
+    __syncthreads();
+    if (tid == 0) {
+        unsigned int run = 0;
+        for (int b = 0; b < 64; b++) {
+            s_base[b] = run;
+            run += s_count[b];
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += 1024) {
+        const int b = 63 - int((unsigned long long)cost[k] * 64ull / top);
+        order[atomicAdd(&s_base[b], 1u)] = k;
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += 1024) cost[k] = 0;
+}
+
+hipError_t launch_tile_order(unsigned int* cost, int n, int32_t* order, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    rtk_tile_order_kernel<<<dim3(1), dim3(1024), 0, stream>>>(cost, n, order);
+    return hipGetLastError();
 }
 
 // Partial sums -> pixels.  For every pixel of this rank: add its chunks in index
@@ -1226,7 +1276,8 @@ static size_t lds_image_bytes(const SceneView<real>& sc) {
 
 template <typename real, uint32_t FEAT, bool COUNT, bool IN_LDS>
 static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>* cam, const TileMap& tmap, uint32_t seed, void* partial,
-                             unsigned long long* counters, unsigned int* tile_counter, uint32_t diag, hipStream_t stream) {
+                             unsigned long long* counters, unsigned int* tile_counter, const int32_t* tile_order, unsigned int* tile_cost, uint32_t diag,
+                             hipStream_t stream) {
     const int n_items = tmap.n_tiles_local * tmap.n_chunks;
     if (n_items <= 0) return hipSuccess;
     auto kernel = rtk_render_kernel<real, FEAT, COUNT, IN_LDS>;
@@ -1236,7 +1287,7 @@ static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>* c
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(tile_counter, 0, sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
-    kernel<<<dim3(blocks), dim3(threads), lds, stream>>>(sc, cam, tmap, seed, static_cast<real*>(partial), counters, tile_counter, diag);
+    kernel<<<dim3(blocks), dim3(threads), lds, stream>>>(sc, cam, tmap, seed, static_cast<real*>(partial), counters, tile_counter, tile_order, tile_cost, diag);
     return hipGetLastError();
 }
 
@@ -1247,25 +1298,26 @@ bool program_fits_lds(const SceneView<real>& sc) {
 
 template <typename real>
 hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>* cam, const TileMap& tmap, uint32_t seed, uint32_t features, bool count,
-                         bool allow_lds, uint32_t diag, void* partial, unsigned long long* counters, unsigned int* tile_counter, hipStream_t stream) {
+                         bool allow_lds, uint32_t diag, void* partial, unsigned long long* counters, unsigned int* tile_counter,
+                         const int32_t* tile_order, unsigned int* tile_cost, hipStream_t stream) {
     const bool lds = allow_lds && program_fits_lds(sc);
-    if (count) return launch_one<real, kFeatAll, true, false>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream);
+    if (count) return launch_one<real, kFeatAll, true, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
     if (features == kFeatLean)
-        return lds ? launch_one<real, kFeatLean, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream)
-                   : launch_one<real, kFeatLean, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream);
+        return lds ? launch_one<real, kFeatLean, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream)
+                   : launch_one<real, kFeatLean, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
     if ((features & ~kFeatQuadBox) == 0)
-        return lds ? launch_one<real, kFeatQuadBox, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream)
-                   : launch_one<real, kFeatQuadBox, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream);
+        return lds ? launch_one<real, kFeatQuadBox, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream)
+                   : launch_one<real, kFeatQuadBox, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
     if ((features & ~kFeatMesh) == 0)
-        return lds ? launch_one<real, kFeatMesh, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream)
-                   : launch_one<real, kFeatMesh, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream);
-    return lds ? launch_one<real, kFeatAll, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream)
-               : launch_one<real, kFeatAll, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, diag, stream);
+        return lds ? launch_one<real, kFeatMesh, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream)
+                   : launch_one<real, kFeatMesh, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
+    return lds ? launch_one<real, kFeatAll, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream)
+               : launch_one<real, kFeatAll, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
 }
 template hipError_t launch_render<double>(const SceneView<double>&, const CameraRec<double>*, const TileMap&, uint32_t, uint32_t, bool, bool, uint32_t, void*,
-                                          unsigned long long*, unsigned int*, hipStream_t);
+                                          unsigned long long*, unsigned int*, const int32_t*, unsigned int*, hipStream_t);
 template hipError_t launch_render<float>(const SceneView<float>&, const CameraRec<float>*, const TileMap&, uint32_t, uint32_t, bool, bool, uint32_t, void*,
-                                         unsigned long long*, unsigned int*, hipStream_t);
+                                         unsigned long long*, unsigned int*, const int32_t*, unsigned int*, hipStream_t);
 template bool program_fits_lds<double>(const SceneView<double>&);
 template bool program_fits_lds<float>(const SceneView<float>&);
 

@@ -133,6 +133,10 @@ def test_seed_and_determinism(rt, renderer, scenes):
     c, _, _ = renderer.render_host(cam, seed=6)
     assert np.array_equal(a, b)          # run-to-run bit-identical (RNG keyed by pixel and sample only)
     assert not np.array_equal(a, c)
+    # `b` was rendered in the tile order learned from `a` (most expensive tiles first), `d` in fixed row-major order:
+    # the order in which tiles are handed to waves must never show in the image
+    d, _, _ = renderer.render_host(cam, seed=5, variant=4)
+    assert np.array_equal(a, d)
 
 
 @pytest.mark.parametrize("n_ranks,real", [(2, "f64"), (3, "f64"), (8, "f64"), (4, "f32")])

@@ -789,11 +789,12 @@ RTK_DEV void store_partial(real* __restrict__ partial, int item, int pix, V3<rea
 
 // Workgroup-size bound = register budget: 1024 threads -> 4 waves per SIMD, 128 VGPRs; 768 -> 3 waves, 168 VGPRs;
 // 512 -> 2 waves, 256 VGPRs.  Measured on C2 (lean f64 kernel): 2 waves 93.8 ms, 3 waves 73.5 ms, 4 waves 68.5 ms
-// per frame (the 4-wave build spills a few values in the shade path).  The full-feature f64 kernel needs far more
-// registers (it spilled ~560 B/lane at 168) and stays at 2 waves per SIMD.
+// per frame (the 4-wave build spills a few values in the shade path).  Same-box A/B for the other f64 kernels
+// (tools/ab/run_ab.sh): quad/box subset on C3 43.3 ms at 4 waves vs 48.7 at 3; mesh subset on C4 no difference;
+// the full-feature kernel, which needs far more registers (~560 B/lane of spills at 168), is fastest at 2 waves.
 template <typename real, uint32_t FEAT>
 constexpr int max_threads() {
-    if (sizeof(real) == 8) return FEAT == kFeatAll ? 512 : (FEAT == kFeatLean ? 1024 : 768);
+    if (sizeof(real) == 8) return FEAT == kFeatAll ? 512 : ((FEAT == kFeatLean || FEAT == kFeatQuadBox) ? 1024 : 768);
     return 768;
 }
 

@@ -10,7 +10,8 @@ for n in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Iinclude -I$C $C/rtk_api.cpp gpurun_out/ab/$n/rtk_trace.hip -o gpurun_out/ab/$n.so &
 done
 wait
+CFG=${AB_CONFIG:-c2}; SPP=${AB_SPP:-0}; REAL=${AB_REAL:-f64}
 for i in 1 2; do
-  for n in "$@"; do RTK_HIP_LIB=$PWD/gpurun_out/ab/$n.so python tools/render_once.py c2 f64 3 | tail -1 | cut -c1-48 | sed "s/^/$n: /"; done
-  python tools/render_once.py c2 f64 3 | tail -1 | cut -c1-48 | sed "s/^/current: /"
+  for n in "$@"; do RTK_HIP_LIB=$PWD/gpurun_out/ab/$n.so python tools/render_once.py $CFG $REAL 3 $SPP | tail -1 | cut -c1-48 | sed "s/^/$n ($CFG): /"; done
+  python tools/render_once.py $CFG $REAL 3 $SPP | tail -1 | cut -c1-48 | sed "s/^/current ($CFG): /"
 done

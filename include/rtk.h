@@ -197,7 +197,11 @@ typedef struct rtk_render_opts {
     int32_t real_mode;      /* rtk_real_mode */
     int32_t rank, n_ranks;  /* tile ownership; (0,1) = whole image */
     int32_t count_work;     /* != 0: also accumulate rtk_work_counters (slower; not for timing) */
-    int32_t variant;        /* kernel variant selector, 0 = default */
+    int32_t variant;        /* 0 = default.  Bit flags for A/B measurements and tests; none of them changes what is
+                             * computed: 1 = keep the traversal program in global memory (no LDS staging);
+                             * 2 = one sample chunk per pixel; 4 = fixed row-major tile order (no cost-ordered
+                             * hand-out); bits 3-4 = chunk size (0: 4 samples, 1: 8, 2: 2, 3: 16);
+                             * bits 8-13 = scheduler loop-exit thresholds (see csrc/rtk_trace.hip) */
     void* stream;           /* hipStream_t, NULL = default stream */
 } rtk_render_opts;
 

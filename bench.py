@@ -13,6 +13,13 @@ are resident in HBM before the timed region; the framebuffer stays on the device
 value = W*H*spp*K / max-over-ranks(time) / 1e6, whole job.  Total work is fixed as
 N grows, so scaling is "strong".
 
+Visiting order: by default ("--order auto") the scene is rendered in the fast order of
+rtk_scene_optimize (same primitives, SAH grouping, fewer aabb::hit calls per ray) when
+that is provably bit-identical to the reference's bvh_node order (no constant_medium, no
+triangle: C2, C3), otherwise in the reference order.  The other order is rendered too,
+outside the timed region, and reported under "other_order" with its own rate; when the
+fast order claims exactness the two framebuffers must be byte-identical or the run fails.
+
 The headline dtype is f64: the reference computes in double (vec3.h:7) and the
 parity bar (RMSE < 1e-4 against the CPU at matched seed) is only meaningful at
 that precision.  The f32 kernel's rate is reported beside it under
@@ -53,6 +60,8 @@ def parse_args():
     p.add_argument("--height", type=int, default=0)
     p.add_argument("--spp", type=int, default=0)
     p.add_argument("--variant", type=int, default=0, help="kernel variant (dev A/B)")
+    p.add_argument("--order", default="auto", choices=["auto", "reference", "fast"],
+                   help="visiting order: the reference's bvh_node order, rtk_scene_optimize's fast order, or fast where it is bit-identical (auto)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-f32", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
@@ -139,12 +148,17 @@ def main():
     cam = scene.camera(args.width, args.height, args.spp, 0)
     W, H, spp, depth = cam.image_width, cam.image_height, cam.samples_per_pixel, cam.max_depth
     reduced = bool(args.width or args.height or args.spp)
+    fast_scene = scene.fast_order(cam.center)
+    use_fast = args.order == "fast" or (args.order == "auto" and fast_scene.exact)
+    order_name = "fast (rtk_scene_optimize)" if use_fast else "reference (bvh.h)"
     renderer = rt.Renderer(local_rank)
-    renderer.upload(scene)
+    renderer.upload(fast_scene if use_fast else scene)
+    other_renderer = rt.Renderer(local_rank)
+    other_renderer.upload(scene if use_fast else fast_scene)
     info = renderer.scene_info()
     stream = torch.cuda.current_stream().cuda_stream
 
-    def make_step(real_mode):
+    def make_step(real_mode, renderer=renderer):
         dtype = torch.float64 if real_mode == rt.RTK_REAL_F64 else torch.float32
         tpr = tiling.tiles_per_rank(W, H, n)
         image = torch.empty((H, W, 3), dtype=dtype, device=dev) if rank == 0 else None
@@ -179,8 +193,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(real_mode, steps, warmup):
-        step, image = make_step(real_mode)
+    def timed(real_mode, steps, warmup, renderer=renderer):
+        step, image = make_step(real_mode, renderer)
         for _ in range(warmup):
             step()
         barrier()
@@ -200,13 +214,27 @@ def main():
         barrier()
         return elapsed, sum(kernel_ms) / len(kernel_ms), image
 
+    import hashlib
+
     elapsed, kernel_ms, image = timed(rt.RTK_REAL_F64, args.steps, args.warmup)
     checksum = None
     if rank == 0:  # a digest of the framebuffer: must not depend on the number of GPUs
-        import hashlib
         checksum = hashlib.sha256(image.cpu().numpy().tobytes()).hexdigest()[:16]
     samples_per_step = W * H * spp
     value = samples_per_step * args.steps / elapsed / 1e6
+
+    # ---- the other visiting order, outside the timed region: its rate, and the proof that both orders give the same bytes
+    other_steps = max(1, min(args.steps, 3))
+    o_elapsed, o_kernel_ms, o_image = timed(rt.RTK_REAL_F64, other_steps, 1, other_renderer)
+    other = None
+    if rank == 0:
+        o_sum = hashlib.sha256(o_image.cpu().numpy().tobytes()).hexdigest()[:16]
+        other = {"order": "reference (bvh.h)" if use_fast else "fast (rtk_scene_optimize)", "value": round(samples_per_step * other_steps / o_elapsed / 1e6, 2),
+                 "unit": "Msamples/s", "kernel_ms": round(o_kernel_ms, 4), "framebuffer_sha256": o_sum, "identical_framebuffer": o_sum == checksum,
+                 "fast_order_exact": fast_scene.exact, "fast_order_info": fast_scene.info}
+        if fast_scene.exact and o_sum != checksum:
+            raise SystemExit(f"fast order claims bit-identity but the framebuffers differ: {checksum} vs {o_sum}")
+    del o_image
 
     # ---- roofline of the render kernel on rank 0: exact work counters -> algorithmic bytes per launch
     roofline = None
@@ -228,7 +256,7 @@ def main():
         if os.path.exists(tfile):
             try:
                 rec = json.load(open(tfile))
-                if rec.get("workload") == f"{scene_name} {W}x{H}x{spp}" and rec.get("n_gpus") == n and rec.get("dtype") == "f64":
+                if rec.get("workload") == f"{scene_name} {W}x{H}x{spp}" and rec.get("n_gpus") == n and rec.get("dtype") == "f64" and rec.get("order", "reference (bvh.h)") == order_name:
                     traffic = rec.get("hbm_bytes_per_launch")
                     # what actually bounds the kernel: VALU instruction issue (one wave-instruction per SIMD per
                     # ~4 cycles for this f64/select mix), on partially filled waves
@@ -268,10 +296,11 @@ def main():
             "config": {"workload": f"{scene_name} {W}x{H}x{spp}spp depth {depth} (BASELINE configs[{int(args.config[1]) - 1}])",
                        "tiles": "8x8 px per wave, interleaved over ranks", "parallelism": f"image tiles over {n} GPU(s) + 1 gather" if n > 1 else "1 GPU",
                        "scene_seed": rt.SCENE_SEED, "render_seed": rt.RENDER_SEED, "program_ops": info["program_ops"], "reduced": reduced,
-                       "variant": args.variant},
+                       "variant": args.variant, "order": order_name},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "f32_mode": f32_mode,
+            "other_order": other,
             "speedup_vs_cpu_baseline": (round(value / cpu["value"], 1) if cpu and cpu.get("value") else None),
             "framebuffer_sha256": checksum,
         }

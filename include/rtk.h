@@ -241,6 +241,41 @@ int rtk_destroy(rtk_ctx* ctx);
  * and uploads f64 and f32 copies.  Replaces any previously uploaded scene. */
 int rtk_scene_upload(rtk_ctx* ctx, const rtk_scene_desc* scene);
 
+/* Fast visiting order -----------------------------------
+ * Host-only pass, no device needed.  Re-groups the SAME primitives of `scene`
+ * into a surface-area-heuristic hierarchy with a fixed near-child-first order
+ * (near = closer to opts->eye) and returns it as a new description made of
+ * RTK_NODE_BVH / RTK_NODE_LIST nodes; upload that instead of `scene` to render
+ * with fewer aabb::hit calls per ray.  The reference's own order (bvh.h:13-45
+ * median split, bvh.h:64-72 left then right) stays the default everywhere else.
+ * The closest hit of every ray is preserved, so for scenes without a
+ * constant_medium and without triangles the image is bit-identical (info->exact
+ * = 1); a medium draws a random number inside hit() (constant_medium.h:40), so
+ * with media the RNG order changes and parity is statistical; with triangles see
+ * rtk_optimize_info.has_triangles.  The work counters differ by design.  *out_scene borrows every table of `scene` except nodes,
+ * list_children and bvh_boxes: keep `scene` alive while it is in use, release it
+ * with rtk_scene_optimized_free. */
+typedef struct rtk_optimize_opts {
+    int32_t has_eye;        /* != 0: order children by distance to `eye` (camera::center, Camera.txt:125) */
+    int32_t max_leaf;       /* most primitives tested in a row without a box of their own (0 = 4) */
+    rtk_vec3 eye;
+    double prim_cost_scale; /* scales the cost of a primitive test relative to a slab test in the SAH (0 = 1.0) */
+} rtk_optimize_opts;
+
+typedef struct rtk_optimize_info {
+    int32_t exact;              /* 1: images are bit-identical to the reference order (no medium, no triangle) */
+    int32_t has_media;          /* a constant_medium draws inside hit(): the RNG order changes, parity is statistical */
+    int32_t has_triangles;      /* triangle::hit's float determinant (triangle.h:72,77): identical except where the
+                                 * reference's own boxes cull a hit that triangle::hit accepts (order-dependent) */
+    int32_t n_bvh_nodes_in, n_bvh_nodes_out, _pad;
+    double expected_cost;       /* SAH estimate, in slab tests, of one closest-hit query */
+    double box_margin;          /* every new box is grown by this much (2^-40 of the scene extent) */
+} rtk_optimize_info;
+
+int rtk_scene_optimize(const rtk_scene_desc* scene, const rtk_optimize_opts* opts,
+                       rtk_scene_desc** out_scene, rtk_optimize_info* info /* may be NULL */);
+void rtk_scene_optimized_free(rtk_scene_desc* scene);
+
 /* Number of tiles rank `rank` of `n_ranks` owns for a W x H image, and the
  * element count of its compact tile buffer (tiles * 3 * 64 reals). */
 int64_t rtk_tiles_per_rank(int image_width, int image_height, int n_ranks);

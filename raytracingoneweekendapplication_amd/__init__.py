@@ -70,6 +70,18 @@ class RenderOpts(C.Structure):
     ]
 
 
+class OptimizeOpts(C.Structure):
+    """rtk_optimize_opts (include/rtk.h)."""
+
+    _fields_ = [("has_eye", C.c_int32), ("max_leaf", C.c_int32), ("eye", Vec3), ("prim_cost_scale", C.c_double)]
+
+
+class OptimizeInfo(C.Structure):
+    _fields_ = [("exact", C.c_int32), ("has_media", C.c_int32), ("has_triangles", C.c_int32),
+                ("n_bvh_nodes_in", C.c_int32), ("n_bvh_nodes_out", C.c_int32), ("_pad", C.c_int32),
+                ("expected_cost", C.c_double), ("box_margin", C.c_double)]
+
+
 COUNTER_FIELDS = (
     "samples", "segments", "box_tests", "sphere_tests", "quad_tests", "triangle_tests",
     "xform_enters", "medium_tests", "surface_hits", "noise_calls", "texel_fetches", "rng_draws",
@@ -154,6 +166,9 @@ def hip_lib() -> C.CDLL:
         lib.rtk_render_host.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rtk_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.rtk_debug_closest_hit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.rtk_scene_optimize.argtypes = [C.c_void_p, C.POINTER(OptimizeOpts), C.POINTER(C.c_void_p), C.POINTER(OptimizeInfo)]
+        lib.rtk_scene_optimized_free.restype = None
+        lib.rtk_scene_optimized_free.argtypes = [C.c_void_p]
         lib.rtk_kernel_name.restype = C.c_char_p
         lib.rtk_kernel_name.argtypes = [C.c_void_p, C.c_int, C.c_int]
         if lib.rtk_abi_version() != RTK_ABI_VERSION:
@@ -202,10 +217,52 @@ class Scene:
             raise ValueError(f"cannot derive a {width}x{height} camera for {self.name} (rc={rc})")
         return cam
 
+    def fast_order(self, eye: Optional[Vec3] = None, max_leaf: int = 0, prim_cost_scale: float = 0.0) -> "FastOrderScene":
+        """The same primitives re-grouped by rtk_scene_optimize (host-only pass of librtk_hip.so)."""
+        return FastOrderScene(self, eye, max_leaf, prim_cost_scale)
+
     def close(self) -> None:
         if self._h:
             host_lib().rtkh_scene_free(self._h)
             self._h = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FastOrderScene:
+    """rtk_scene_optimize output: a description that borrows the tables of `base` (kept alive here).
+
+    ``exact`` says whether rendering it gives bit-identical images to the reference order (no constant_medium).
+    """
+
+    def __init__(self, base: Scene, eye: Optional[Vec3] = None, max_leaf: int = 0, prim_cost_scale: float = 0.0):
+        self.base = base
+        self.name = base.name + "+fast_order"
+        opts = OptimizeOpts(1 if eye is not None else 0, max_leaf, eye if eye is not None else Vec3(0, 0, 0), prim_cost_scale)
+        out, info = C.c_void_p(), OptimizeInfo()
+        rc = hip_lib().rtk_scene_optimize(base.desc_ptr, C.byref(opts), C.byref(out), C.byref(info))
+        if rc != 0 or not out.value:
+            raise RtkError(rc, "rtk_scene_optimize failed")
+        self._h = out.value
+        self.exact = bool(info.exact)
+        self.info = {"exact": bool(info.exact), "has_media": bool(info.has_media), "has_triangles": bool(info.has_triangles), "n_bvh_nodes_in": info.n_bvh_nodes_in, "n_bvh_nodes_out": info.n_bvh_nodes_out,
+                     "expected_cost": info.expected_cost, "box_margin": info.box_margin}
+
+    @property
+    def desc_ptr(self) -> int:
+        return self._h
+
+    def camera(self, *args, **kwargs) -> Camera:
+        return self.base.camera(*args, **kwargs)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            hip_lib().rtk_scene_optimized_free(self._h)
+            self._h = None
 
     def __del__(self):
         try:
@@ -247,7 +304,7 @@ class Renderer:
         if rc != 0:
             raise RtkError(rc, self._lib.rtk_last_error().decode())
 
-    def upload(self, scene: Scene) -> None:
+    def upload(self, scene) -> None:
         self._check(self._lib.rtk_scene_upload(self._ctx, scene.desc_ptr))
 
     def scene_info(self) -> dict:

@@ -1,0 +1,556 @@
+// rtk_optimize.cpp -- the "fast order" scene optimiser behind rtk_scene_optimize
+// (include/rtk.h).  Host code only: no device is touched, so it also runs where
+// there is no GPU (the CPU tests execute the oracle on its output).
+//
+// the reference's bvh_node (bvh.h:13-45) splits the object
+// list at the median of the longest axis and bvh_node::hit (bvh.h:64-72) always
+// visits left then right.  On the book-1 scene that costs ~40 aabb::hit calls per
+// ray.  This pass re-groups the SAME primitives -- nothing about a primitive, a
+// material or an instance transform changes -- into a surface-area-heuristic
+// hierarchy, and fixes the visiting order of every node's two children so that
+// the child nearer to the eye comes first (a closest-hit found early shrinks the
+// interval that every later slab test sees, exactly as `hit_left ? rec.t :
+// ray_t.max` does in bvh.h:69).  The result is again an rtk_scene_desc made of
+// RTK_NODE_BVH / RTK_NODE_LIST nodes over the same primitive tables, so the same
+// linear traversal program, the same kernels and the same oracle run on it.
+//
+// What is preserved: the closest hit of every ray, hence -- for scenes without a
+// constant_medium -- every pixel bit for bit (the RNG stream of a sample does not
+// depend on the visiting order unless a medium draws inside hit(),
+// constant_medium.h:40).  What changes: the work counters (fewer box tests), and
+// with media the order of those draws (parity becomes statistical; the optimiser
+// reports it through rtk_optimize_info.exact).  Triangles: triangle::hit scales
+// its hit distance by a float reciprocal of a float determinant (triangle.h:72,77),
+// so an accepted hit can lie ~1e-7 of the travelled distance outside the triangle's
+// exact box; whether the reference's own boxes let such a hit through depends on
+// its visiting order, which no other hierarchy can reproduce.  Triangle boxes are
+// grown so that no accepted hit is ever culled here (the fast order finds the
+// closest of ALL hits triangle::hit accepts), and exact is reported as 0 for
+// scenes with triangles: on the C4 mesh scene 1 sample in 5.3e8 took a different
+// path before the boxes were grown.  Ties: two different primitives
+// hit at exactly the same t are resolved by visiting order in the reference
+// (strict `surrounds` for spheres, sphere.h:44-48; inclusive `contains` for
+// quads/triangles, quad.h:39, triangle.h:91); the re-ordered hierarchy may
+// resolve such a tie differently.  None of the BASELINE scenes has one (tested
+// by whole-image equality against the reference order).
+//
+// Boxes: every primitive box is computed the way the reference computes it
+// (sphere.h:17,24-26; quad.h:21-25; triangle.h:59; hittable.h:43,75-98;
+// constant_medium.h:55) and then grown by a relative margin of 2^-40 of the scene
+// extent, so a slab test (aabb.h:61-85) in a re-grouped node can never cull a hit
+// the reference's own boxes would have let through because of rounding.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <unordered_set>
+#include <vector>
+
+#include "rtk.h"
+
+namespace {
+
+struct Box {
+    double lo[3], hi[3];
+    static Box empty() {
+        const double inf = std::numeric_limits<double>::infinity();
+        return Box{{inf, inf, inf}, {-inf, -inf, -inf}};
+    }
+    void grow(const Box& o) {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = std::min(lo[a], o.lo[a]);
+            hi[a] = std::max(hi[a], o.hi[a]);
+        }
+    }
+    void grow(double x, double y, double z) {
+        const double p[3] = {x, y, z};
+        for (int a = 0; a < 3; a++) {
+            lo[a] = std::min(lo[a], p[a]);
+            hi[a] = std::max(hi[a], p[a]);
+        }
+    }
+    bool valid() const { return lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]; }
+    double area() const {
+        if (!valid()) return 0.0;
+        const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return 2.0 * (dx * dy + dy * dz + dz * dx);
+    }
+    double centre(int a) const { return 0.5 * (lo[a] + hi[a]); }
+    // squared distance from p to the box (0 inside)
+    double distance2(const double p[3]) const {
+        double d2 = 0;
+        for (int a = 0; a < 3; a++) {
+            const double d = p[a] < lo[a] ? lo[a] - p[a] : (p[a] > hi[a] ? p[a] - hi[a] : 0.0);
+            d2 += d * d;
+        }
+        return d2;
+    }
+};
+
+struct Item {
+    int32_t node;  // index into the OUTPUT node table
+    Box box;
+    double cost;   // relative cost of testing it once
+};
+
+struct Holder {
+    rtk_scene_desc desc;
+    std::vector<rtk_node> nodes;
+    std::vector<int32_t> children;
+    std::vector<rtk_aabb> boxes;
+};
+
+struct Optimizer {
+    const rtk_scene_desc& in;
+    const rtk_optimize_opts& opts;
+    Holder& out;
+    std::vector<int32_t> memo;       // input node -> output node (a shared subtree stays shared)
+    std::vector<Box> memo_box;       // box of that output node, in the parent's space
+    std::vector<double> memo_cost;
+    std::vector<char> on_stack;
+    std::vector<char> memo_media;    // the subtree of that input node contains a constant_medium
+    bool failed = false;
+    bool has_media = false;
+    double margin = 0.0, tri_margin = 0.0;
+    bool has_triangles = false;
+    int64_t n_bvh_in = 0;
+
+    Optimizer(const rtk_scene_desc& i, const rtk_optimize_opts& o, Holder& h)
+        : in(i), opts(o), out(h), memo(size_t(i.n_nodes), -1), memo_box(size_t(i.n_nodes)), memo_cost(size_t(i.n_nodes), 1.0), on_stack(size_t(i.n_nodes), 0), memo_media(size_t(i.n_nodes), 0) {}
+
+    static constexpr double kBoxCost = 1.0;    // one slab test
+    static constexpr double kChainCost = 3.0;  // entering and leaving an instance transform (two chain switches of the kernel)
+    double prim_cost(int32_t kind) const { return opts.prim_cost_scale * base_prim_cost(kind); }
+    static double base_prim_cost(int32_t kind) {  // measured ratios of the kernel's step costs, roughly
+        switch (kind) {
+            case RTK_NODE_SPHERE: return 1.5;
+            case RTK_NODE_QUAD: return 2.5;
+            case RTK_NODE_TRIANGLE: return 2.5;
+            default: return 4.0;
+        }
+    }
+
+    int32_t push_node(int32_t kind, int32_t a, int32_t b, int32_t c) {
+        out.nodes.push_back(rtk_node{kind, a, b, c});
+        return int32_t(out.nodes.size()) - 1;
+    }
+
+    // ---- boxes of the primitives, as the reference's constructors compute them
+    static void pad_axis(double& lo, double& hi) {  // aabb.h:98-105 pad_to_minimums
+        const double delta = 0.0001;
+        if (hi - lo < delta) {
+            const double padding = delta / 2;
+            lo -= padding;
+            hi += padding;
+        }
+    }
+    bool primitive_box(const rtk_node& n, Box& b) {
+        b = Box::empty();
+        if (n.kind == RTK_NODE_SPHERE) {
+            if (n.a < 0 || n.a >= in.n_spheres) return false;
+            const rtk_sphere& s = in.spheres[n.a];
+            const double r = s.radius;
+            b.grow(s.center0.x - r, s.center0.y - r, s.center0.z - r);
+            b.grow(s.center0.x + r, s.center0.y + r, s.center0.z + r);
+            const double ex = s.center0.x + s.center_dir.x, ey = s.center0.y + s.center_dir.y, ez = s.center0.z + s.center_dir.z;
+            b.grow(ex - r, ey - r, ez - r);
+            b.grow(ex + r, ey + r, ez + r);
+        } else if (n.kind == RTK_NODE_QUAD) {
+            if (n.a < 0 || n.a >= in.n_quads) return false;
+            const rtk_quad& q = in.quads[n.a];
+            b.grow(q.Q.x, q.Q.y, q.Q.z);
+            b.grow(q.Q.x + q.u.x, q.Q.y + q.u.y, q.Q.z + q.u.z);
+            b.grow(q.Q.x + q.v.x, q.Q.y + q.v.y, q.Q.z + q.v.z);
+            b.grow(q.Q.x + q.u.x + q.v.x, q.Q.y + q.u.y + q.v.y, q.Q.z + q.u.z + q.v.z);
+        } else {
+            if (n.a < 0 || n.a >= in.n_triangles) return false;
+            const rtk_triangle& t = in.triangles[n.a];
+            b.grow(t.p0.x, t.p0.y, t.p0.z);
+            b.grow(t.p1.x, t.p1.y, t.p1.z);
+            b.grow(t.p2.x, t.p2.y, t.p2.z);
+        }
+        for (int a = 0; a < 3; a++) pad_axis(b.lo[a], b.hi[a]);
+        if (n.kind == RTK_NODE_TRIANGLE) {
+            // triangle::hit scales u, v and t by a FLOAT 1/det of a float det (triangle.h:72,77): the accepted hit
+            // distance is off by up to 2^-23 relative, so the hit point can lie outside the triangle's exact box
+            // by that fraction of the distance the ray has travelled.  Grow by that, or a box would cull a hit
+            // triangle::hit itself accepts.
+            b = grown(b, tri_margin);
+        }
+        return true;
+    }
+
+    // Items of a group: everything reachable through nested LIST / BVH nodes without crossing an instance
+    // transform or a medium.  Those become single items (optimised recursively, in their own space).
+    bool gather(int32_t node, std::vector<Item>& items, std::unordered_set<int32_t>& present, int depth) {
+        if (failed || node < 0 || node >= in.n_nodes || depth > 4096) return !(failed = true);
+        const rtk_node& n = in.nodes[node];
+        if (n.kind == RTK_NODE_LIST) {
+            if (n.a < 0 || n.b < 0 || int64_t(n.a) + n.b > in.n_list_children) return !(failed = true);
+            for (int32_t k = 0; k < n.b; k++)
+                if (!gather(in.list_children[n.a + k], items, present, depth + 1)) return false;
+            return true;
+        }
+        if (n.kind == RTK_NODE_BVH) {
+            n_bvh_in++;
+            // a span of one stores the object twice (bvh.h:30-32); the duplicate is sorted out per item below
+            return gather(n.a, items, present, depth + 1) && gather(n.b, items, present, depth + 1);
+        }
+        Box b;
+        double cost;
+        const int32_t o = convert(node, b, cost, depth + 1);
+        if (o < 0) return false;
+        // The same object may be listed twice (a span of one: bvh.h:30-32).  Testing a surface twice finds nothing
+        // new, so one test is kept; a constant_medium draws a fresh random number per test (constant_medium.h:40),
+        // so its second test is a second, independent chance to scatter and stays.
+        if (!present.insert(o).second && !memo_media[node]) return true;
+        items.push_back(Item{o, b, cost});
+        return true;
+    }
+
+    // Output node for a non-group input node (primitive, transform, medium); groups go through build_group.
+    int32_t convert(int32_t node, Box& box, double& cost, int depth) {
+        if (failed || node < 0 || node >= in.n_nodes || depth > 4096) {
+            failed = true;
+            return -1;
+        }
+        if (memo[node] >= 0) {
+            box = memo_box[node];
+            cost = memo_cost[node];
+            if (memo_media[node]) has_media = true;
+            return memo[node];
+        }
+        if (on_stack[node]) {  // a cycle
+            failed = true;
+            return -1;
+        }
+        on_stack[node] = 1;
+        const rtk_node& n = in.nodes[node];
+        int32_t o = -1;
+        switch (n.kind) {
+            case RTK_NODE_SPHERE:
+            case RTK_NODE_QUAD:
+            case RTK_NODE_TRIANGLE:
+                if (n.kind == RTK_NODE_TRIANGLE) has_triangles = true;
+                if (!primitive_box(n, box)) {
+                    failed = true;
+                    break;
+                }
+                cost = prim_cost(n.kind);
+                o = push_node(n.kind, n.a, n.b, n.c);
+                break;
+            case RTK_NODE_LIST:
+            case RTK_NODE_BVH: {
+                const bool media_before = has_media;
+                has_media = false;
+                o = build_group(node, box, cost, depth);
+                memo_media[node] = has_media ? 1 : 0;  // some item of the group (recursively) is or contains a medium
+                has_media = has_media || media_before;
+                break;
+            }
+            case RTK_NODE_TRANSLATE: {
+                if (n.a < 0 || n.a >= in.n_translates) {
+                    failed = true;
+                    break;
+                }
+                Box cb;
+                double cc;
+                const int32_t child = convert(n.b, cb, cc, depth + 1);
+                if (child < 0) break;
+                const rtk_vec3& off = in.translates[n.a].offset;  // hittable.h:43: bbox = object->bounding_box() + offset
+                box = cb;
+                box.lo[0] += off.x; box.hi[0] += off.x;
+                box.lo[1] += off.y; box.hi[1] += off.y;
+                box.lo[2] += off.z; box.hi[2] += off.z;
+                cost = cc + kChainCost;
+                o = push_node(RTK_NODE_TRANSLATE, n.a, child, 0);
+                memo_media[node] = memo_media[n.b];
+                break;
+            }
+            case RTK_NODE_ROTATE_Y: {
+                if (n.a < 0 || n.a >= in.n_rotates) {
+                    failed = true;
+                    break;
+                }
+                Box cb;
+                double cc;
+                const int32_t child = convert(n.b, cb, cc, depth + 1);
+                if (child < 0) break;
+                const double s = in.rotates[n.a].sin_theta, c = in.rotates[n.a].cos_theta;
+                box = Box::empty();  // hittable.h:75-98: the box of the eight rotated corners
+                for (int i = 0; i < 2; i++)
+                    for (int j = 0; j < 2; j++)
+                        for (int k = 0; k < 2; k++) {
+                            const double x = i ? cb.hi[0] : cb.lo[0], y = j ? cb.hi[1] : cb.lo[1], z = k ? cb.hi[2] : cb.lo[2];
+                            box.grow(c * x + s * z, y, -s * x + c * z);
+                        }
+                cost = cc + kChainCost;
+                o = push_node(RTK_NODE_ROTATE_Y, n.a, child, 0);
+                memo_media[node] = memo_media[n.b];
+                break;
+            }
+            case RTK_NODE_MEDIUM: {
+                if (n.a < 0 || n.a >= in.n_media) {
+                    failed = true;
+                    break;
+                }
+                has_media = true;
+                Box cb;
+                double cc;
+                const int32_t child = convert(n.b, cb, cc, depth + 1);
+                if (child < 0) break;
+                box = cb;  // constant_medium.h:55
+                cost = 2.0 * cc + 3.0;
+                o = push_node(RTK_NODE_MEDIUM, n.a, child, 0);
+                memo_media[node] = 1;
+                break;
+            }
+            default: failed = true; break;
+        }
+        on_stack[node] = 0;
+        if (o < 0) {
+            failed = true;
+            return -1;
+        }
+        memo[node] = o;
+        memo_box[node] = box;
+        memo_cost[node] = cost;
+        return o;
+    }
+
+    static Box grown(const Box& b, double m) {
+        Box r = b;
+        for (int a = 0; a < 3; a++) {
+            r.lo[a] -= m;
+            r.hi[a] += m;
+        }
+        return r;
+    }
+
+    int32_t emit_list(const std::vector<Item>& items, size_t begin, size_t end) {
+        const int32_t first = int32_t(out.children.size());
+        for (size_t k = begin; k < end; k++) out.children.push_back(items[k].node);
+        return push_node(RTK_NODE_LIST, first, int32_t(end - begin), 0);
+    }
+
+    struct Built {
+        int32_t node;
+        double cost;  // expected cost given that the enclosing box was entered
+    };
+
+    // One side of a split: the cheaper of "test the items one after the other" and "a box, then recurse".
+    Built represent(std::vector<Item>& items, size_t begin, size_t end, const Box& parent) {
+        if (end - begin == 1) {
+            // An expensive item (an instance, a medium) whose own box is much smaller than the box it sits in gets a
+            // slab test of its own: a bvh_node whose second child is an empty list.
+            const Item& it = items[begin];
+            const double pa = parent.area();
+            const double boxed = kBoxCost + (pa > 0 ? std::min(1.0, it.box.area() / pa) : 1.0) * it.cost;
+            if (boxed < it.cost) {
+                const Box padded = grown(it.box, margin);
+                out.boxes.push_back(rtk_aabb{padded.lo[0], padded.hi[0], padded.lo[1], padded.hi[1], padded.lo[2], padded.hi[2]});
+                const int32_t nothing = push_node(RTK_NODE_LIST, int32_t(out.children.size()), 0, 0);
+                return Built{push_node(RTK_NODE_BVH, it.node, nothing, int32_t(out.boxes.size()) - 1), boxed};
+            }
+            return Built{it.node, it.cost};
+        }
+        double linear = 0;
+        Box b = Box::empty();
+        for (size_t k = begin; k < end; k++) {
+            linear += items[k].cost;
+            b.grow(items[k].box);
+        }
+        const size_t nodes_mark = out.nodes.size(), child_mark = out.children.size(), box_mark = out.boxes.size();
+        Built inner = split(items, begin, end, b);
+        const double pa = parent.area();
+        const double boxed = kBoxCost + (pa > 0 ? std::min(1.0, b.area() / pa) : 1.0) * inner.cost;
+        if (int(end - begin) <= opts.max_leaf && linear <= boxed) {
+            out.nodes.resize(nodes_mark);  // discard the subtree just built (primitive nodes were created earlier)
+            out.children.resize(child_mark);
+            out.boxes.resize(box_mark);
+            // nearest first inside a leaf as well
+            order_items(items, begin, end);
+            return Built{emit_list(items, begin, end), linear};
+        }
+        return Built{inner.node, boxed};
+    }
+
+    void order_items(std::vector<Item>& items, size_t begin, size_t end) {
+        if (!opts.has_eye) return;
+        const double eye[3] = {opts.eye.x, opts.eye.y, opts.eye.z};
+        std::stable_sort(items.begin() + long(begin), items.begin() + long(end),
+                         [&](const Item& a, const Item& b) { return key(a.box, eye) < key(b.box, eye); });
+    }
+    static double key(const Box& b, const double eye[3]) {
+        const double c[3] = {b.centre(0) - eye[0], b.centre(1) - eye[1], b.centre(2) - eye[2]};
+        return b.distance2(eye) + 1e-6 * (c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    }
+
+    // A BVH node over items[begin, end) (>= 2 items) whose box is `b`: full-sweep SAH on the three axes.
+    Built split(std::vector<Item>& items, size_t begin, size_t end, const Box& b) {
+        const size_t n = end - begin;
+        int best_axis = -1;
+        size_t best_k = 0;
+        double best = std::numeric_limits<double>::infinity();
+        std::vector<double> right_area(n), right_cost(n);
+        for (int axis = 0; axis < 3; axis++) {
+            std::sort(items.begin() + long(begin), items.begin() + long(end), [&](const Item& x, const Item& y) {
+                const double cx = x.box.centre(axis), cy = y.box.centre(axis);
+                return cx != cy ? cx < cy : x.node < y.node;
+            });
+            Box acc = Box::empty();
+            double cost = 0;
+            for (size_t k = n; k-- > 1;) {
+                acc.grow(items[begin + k].box);
+                cost += items[begin + k].cost;
+                right_area[k] = acc.area();
+                right_cost[k] = cost;
+            }
+            acc = Box::empty();
+            cost = 0;
+            for (size_t k = 1; k < n; k++) {  // left = [0, k), right = [k, n)
+                acc.grow(items[begin + k - 1].box);
+                cost += items[begin + k - 1].cost;
+                const double c = acc.area() * cost + right_area[k] * right_cost[k];
+                if (c < best) {
+                    best = c;
+                    best_axis = axis;
+                    best_k = k;
+                }
+            }
+        }
+        if (best_axis != 2)
+            std::sort(items.begin() + long(begin), items.begin() + long(end), [&](const Item& x, const Item& y) {
+                const double cx = x.box.centre(best_axis), cy = y.box.centre(best_axis);
+                return cx != cy ? cx < cy : x.node < y.node;
+            });
+        const size_t mid = begin + best_k;
+        Built l = represent(items, begin, mid, b);
+        Built r = represent(items, mid, end, b);
+        // visiting order of the two children (bvh.h:68-69 visits `left` first): nearer to the eye first; without
+        // an eye, the side that is more likely to be hit
+        bool swap = false;
+        Box lb = Box::empty(), rb = Box::empty();
+        for (size_t k = begin; k < mid; k++) lb.grow(items[k].box);
+        for (size_t k = mid; k < end; k++) rb.grow(items[k].box);
+        if (opts.has_eye) {
+            const double eye[3] = {opts.eye.x, opts.eye.y, opts.eye.z};
+            swap = key(rb, eye) < key(lb, eye);
+        } else {
+            swap = rb.area() > lb.area();
+        }
+        if (swap) std::swap(l, r);
+        const Box padded = grown(b, margin);
+        out.boxes.push_back(rtk_aabb{padded.lo[0], padded.hi[0], padded.lo[1], padded.hi[1], padded.lo[2], padded.hi[2]});
+        const int32_t node = push_node(RTK_NODE_BVH, l.node, r.node, int32_t(out.boxes.size()) - 1);
+        return Built{node, l.cost + r.cost};
+    }
+
+    int32_t build_group(int32_t node, Box& box, double& cost, int depth) {
+        std::vector<Item> items;
+        std::unordered_set<int32_t> present;
+        if (!gather(node, items, present, depth)) return -1;
+        if (items.empty()) {  // an empty list hits nothing (hittable_list.h:22-35)
+            box = Box::empty();
+            cost = 0;
+            return push_node(RTK_NODE_LIST, int32_t(out.children.size()), 0, 0);
+        }
+        box = Box::empty();
+        double linear = 0;
+        for (const Item& it : items) {
+            box.grow(it.box);
+            linear += it.cost;
+        }
+        if (items.size() == 1) {
+            cost = items[0].cost;
+            return items[0].node;
+        }
+        const size_t nodes_mark = out.nodes.size(), child_mark = out.children.size(), box_mark = out.boxes.size();
+        Built inner = split(items, 0, items.size(), box);
+        if (int(items.size()) <= opts.max_leaf && linear <= kBoxCost + inner.cost) {
+            out.nodes.resize(nodes_mark);
+            out.children.resize(child_mark);
+            out.boxes.resize(box_mark);
+            order_items(items, 0, items.size());
+            cost = linear;
+            return emit_list(items, 0, items.size());
+        }
+        cost = kBoxCost + inner.cost;
+        return inner.node;
+    }
+
+    // Scene extent for the rounding margin: boxes of all primitives in their own spaces plus the transforms'
+    // offsets are bounded by the root box and the object-space boxes; use the largest coordinate seen.
+    void compute_margin() {
+        double extent = 0;
+        for (int32_t i = 0; i < in.n_nodes; i++) {
+            const rtk_node& n = in.nodes[i];
+            if (n.kind == RTK_NODE_SPHERE || n.kind == RTK_NODE_QUAD || n.kind == RTK_NODE_TRIANGLE) {
+                Box b;
+                if (!primitive_box(n, b)) continue;
+                for (int a = 0; a < 3; a++) extent = std::max(extent, std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
+            }
+        }
+        for (int32_t i = 0; i < in.n_translates; i++)
+            extent += std::fabs(in.translates[i].offset.x) + std::fabs(in.translates[i].offset.y) + std::fabs(in.translates[i].offset.z);
+        if (opts.has_eye) extent = std::max(extent, std::max(std::fabs(opts.eye.x), std::max(std::fabs(opts.eye.y), std::fabs(opts.eye.z))));
+        margin = std::ldexp(extent > 0 ? extent : 1.0, -40);
+        tri_margin = std::ldexp(extent > 0 ? extent : 1.0, -20);  // 2^-23 relative x scene diameter (<= 2 sqrt(3) extent), doubled
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int rtk_scene_optimize(const rtk_scene_desc* scene, const rtk_optimize_opts* opts_in, rtk_scene_desc** out_scene, rtk_optimize_info* info) {
+    if (!scene || !out_scene) return RTK_ERR_INVALID;
+    *out_scene = nullptr;
+    if (scene->abi_version != RTK_ABI_VERSION || scene->n_nodes <= 0 || !scene->nodes || scene->root < 0 || scene->root >= scene->n_nodes) return RTK_ERR_INVALID;
+    rtk_optimize_opts opts;
+    std::memset(&opts, 0, sizeof opts);
+    if (opts_in) opts = *opts_in;
+    if (opts.max_leaf <= 0) opts.max_leaf = 4;
+    if (!(opts.prim_cost_scale > 0)) opts.prim_cost_scale = 1.0;
+    Holder* h = new (std::nothrow) Holder;
+    if (!h) return RTK_ERR_INVALID;
+    Optimizer op(*scene, opts, *h);
+    op.compute_margin();
+    Box box;
+    double cost = 0;
+    int32_t root = op.convert(scene->root, box, cost, 0);
+    if (root < 0 || op.failed) {
+        delete h;
+        return RTK_ERR_INVALID;
+    }
+    // camera::render is handed a hittable_list (main.cpp:442); keep the root a list so that a single primitive is valid too
+    if (h->nodes[size_t(root)].kind != RTK_NODE_LIST && h->nodes[size_t(root)].kind != RTK_NODE_BVH) {
+        const int32_t first = int32_t(h->children.size());
+        h->children.push_back(root);
+        root = op.push_node(RTK_NODE_LIST, first, 1, 0);
+    }
+    h->desc = *scene;  // primitive, material, texture, image, perlin and light tables are borrowed from the input
+    h->desc.root = root;
+    h->desc.n_nodes = int32_t(h->nodes.size());
+    h->desc.nodes = h->nodes.data();
+    h->desc.n_list_children = int32_t(h->children.size());
+    h->desc.list_children = h->children.data();
+    h->desc.n_bvh_boxes = int32_t(h->boxes.size());
+    h->desc.bvh_boxes = h->boxes.data();
+    if (info) {
+        info->exact = (op.has_media || op.has_triangles) ? 0 : 1;
+        info->has_media = op.has_media ? 1 : 0;
+        info->has_triangles = op.has_triangles ? 1 : 0;
+        info->n_bvh_nodes_in = int32_t(op.n_bvh_in);
+        info->n_bvh_nodes_out = int32_t(h->boxes.size());
+        info->expected_cost = cost;
+        info->box_margin = op.margin;
+    }
+    *out_scene = &h->desc;  // first member: rtk_scene_optimized_free casts the handle back to its holder
+    return RTK_OK;
+}
+
+void rtk_scene_optimized_free(rtk_scene_desc* scene) { delete reinterpret_cast<Holder*>(scene); }
+
+}  // extern "C"

@@ -108,6 +108,8 @@ public:
     int real_mode = RTK_REAL_F64;      // the reference computes in double
     int device = 0;                    // HIP device ordinal
     bool write_image = true;           // write image_name as PNG after rendering
+    bool fast_order = false;           // render the rtk_scene_optimize()d hierarchy (same image when fast_order_exact; fewer slab tests)
+    bool fast_order_exact = false;     // set by render(): the fast order is bit-identical to the reference order for this scene
     double last_render_ms = 0;         // device render time of the last render()
 
     // Camera.txt:136-175.
@@ -161,7 +163,17 @@ public:
         rtk_ctx* ctx = nullptr;
         int rc = rtk_init(device, &ctx);
         if (rc != RTK_OK) return rc;
-        rc = rtk_scene_upload(ctx, &desc);
+        rtk_scene_desc* fast = nullptr;
+        if (fast_order) {  // same primitives, SAH grouping, children ordered by distance to this camera
+            rtk_optimize_opts oo{};
+            oo.has_eye = 1;
+            oo.eye = cam.center;
+            rtk_optimize_info info{};
+            rc = rtk_scene_optimize(&desc, &oo, &fast, &info);
+            fast_order_exact = rc == RTK_OK && info.exact != 0;
+        }
+        if (rc == RTK_OK) rc = rtk_scene_upload(ctx, fast ? fast : &desc);
+        if (fast) rtk_scene_optimized_free(fast);  // the upload copied what it needs
         if (rc == RTK_OK) {
             size_t n = size_t(cam.image_width) * cam.image_height * 3;
             if (linear) linear->assign(n, 0.0);

@@ -288,3 +288,49 @@ def test_device_hit_records_match_reference_known_answers(rt, renderer, tmp_path
         n_hits += int(hit.sum())
     assert n_hits > 800
     assert n_exact >= 0.95 * n_hits   # nearly all records are bit-identical; the rest differ by log()/ulps in media
+
+
+# ---- the fast visiting order (rtk_scene_optimize) --------------------------------------
+@pytest.mark.parametrize("case", IMAGE_CASES, ids=[c[0] for c in IMAGE_CASES])
+def test_fast_order_on_the_device(rt, orc, renderer, scenes, case):
+    """The re-grouped hierarchy through the same kernels: the device agrees with the oracle executing that
+    hierarchy (image, bytes, every work counter), and -- where the pass claims exactness, and on the triangle
+    scenes at these sizes -- with the reference-order image bit for bit."""
+    name, W, H, spp, depth = case
+    scene = scenes(name)
+    cam = scene.camera(W, H, spp, depth)
+    fast = scene.fast_order(cam.center)
+    renderer.upload(fast)
+    gpu, gpu8, counters = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, count=True)
+    ref, ref8, ocnt = orc.render(fast.desc_ptr, cam, RENDER_SEED, 8)
+    assert rmse(gpu, ref) < F64_RMSE_BOUND and np.array_equal(gpu8, ref8) and counters == ocnt
+    if not fast.info["has_media"]:
+        renderer.upload(scene)
+        base, base8, bcnt = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, count=True)
+        assert np.array_equal(gpu, base) and np.array_equal(gpu8, base8)
+        golden = np.load(os.path.join(GOLDEN, f"img_{name}.npz"), allow_pickle=False)
+        assert rmse(gpu, golden["linear"]) < F64_RMSE_BOUND and np.array_equal(gpu8, golden["rgb8"])
+        for key in ("samples", "segments", "surface_hits", "rng_draws"):
+            assert counters[key] == bcnt[key], key
+
+
+def test_fast_order_full_resolution_book1_is_bit_identical_and_cheaper(rt, renderer, scenes):
+    """BASELINE configs[1] at full resolution (reduced spp): same bytes from both orders, about half the slab tests."""
+    import torch
+
+    scene = scenes("book1_final")
+    cam = scene.camera(1920, 1080, 8, 50)
+    dev = torch.device("cuda", 0)
+    out = []
+    for sc in (scene, scene.fast_order(cam.center)):
+        renderer.upload(sc)
+        img = torch.empty((1080, 1920, 3), dtype=torch.float64, device=dev)
+        u8 = torch.empty((1080, 1920, 3), dtype=torch.uint8, device=dev)
+        cnt = torch.zeros(12, dtype=torch.int64, device=dev)
+        renderer.render_device(cam, img.data_ptr(), u8.data_ptr(), d_counters=cnt.data_ptr())
+        torch.cuda.synchronize()
+        out.append((img, u8, dict(zip(rt.COUNTER_FIELDS, cnt.tolist()))))
+    (a, a8, ca), (b, b8, cb) = out
+    assert torch.equal(a, b) and torch.equal(a8, b8)
+    assert ca["rng_draws"] == cb["rng_draws"] and ca["segments"] == cb["segments"] and ca["surface_hits"] == cb["surface_hits"]
+    assert cb["box_tests"] < 0.6 * ca["box_tests"] and cb["sphere_tests"] < ca["sphere_tests"]

@@ -1,6 +1,6 @@
 """Profiling target: upload a config scene and launch the render kernel a fixed number of times.
 
-  python3 tools/render_once.py [config=c2] [real=f64|f32] [launches=2] [spp=0] [variant=0]
+  python3 tools/render_once.py [config=c2] [real=f64|f32] [launches=2] [spp=0] [variant=0] [order=auto|reference|fast]
 Used under rocprofv3 (--kernel-trace --stats, or --pmc passes); prints the event-timed kernel ms.
 """
 import os, sys, tempfile
@@ -13,12 +13,16 @@ real = rt.RTK_REAL_F64 if (len(sys.argv) <= 2 or sys.argv[2] == "f64") else rt.R
 launches = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 spp = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 variant = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+order = sys.argv[6] if len(sys.argv) > 6 else "auto"
 tmp = tempfile.mkdtemp()
 earth = rt.write_synthetic_earth(os.path.join(tmp, "earth_synth.ppm"))
 scene = rt.Scene.build(rt.CONFIG_SCENES[config], rt.SCENE_SEED, earth)
 cam = scene.camera(0, 0, spp, 0)
 r = rt.Renderer(0)
-r.upload(scene)
+fast = scene.fast_order(cam.center)
+use_fast = order == "fast" or (order == "auto" and fast.exact)  # same rule as bench.py
+r.upload(fast if use_fast else scene)
+print(f"order: {'fast (rtk_scene_optimize)' if use_fast else 'reference (bvh.h)'}", flush=True)
 dev = torch.device("cuda", 0)
 H, W = cam.image_height, cam.image_width
 img = torch.empty((H, W, 3), dtype=torch.float64 if real == rt.RTK_REAL_F64 else torch.float32, device=dev)

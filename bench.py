@@ -150,11 +150,14 @@ def main():
     reduced = bool(args.width or args.height or args.spp)
     fast_scene = scene.fast_order(cam.center)
     use_fast = args.order == "fast" or (args.order == "auto" and fast_scene.exact)
-    order_name = "fast (rtk_scene_optimize)" if use_fast else "reference (bvh.h)"
+    order_name = "fast (rtk_scene_upload_fast)" if use_fast else "reference (bvh.h)"
     renderer = rt.Renderer(local_rank)
-    renderer.upload(fast_scene if use_fast else scene)
     other_renderer = rt.Renderer(local_rank)
-    other_renderer.upload(scene if use_fast else fast_scene)
+    for r_, fast_ in ((renderer, use_fast), (other_renderer, not use_fast)):
+        if fast_:
+            r_.upload_fast(scene, cam.center)   # rtk_scene_optimize + upload, fused slab test on the grown boxes
+        else:
+            r_.upload(scene)                    # the reference's own hierarchy and order
     info = renderer.scene_info()
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -229,7 +232,7 @@ def main():
     other = None
     if rank == 0:
         o_sum = hashlib.sha256(o_image.cpu().numpy().tobytes()).hexdigest()[:16]
-        other = {"order": "reference (bvh.h)" if use_fast else "fast (rtk_scene_optimize)", "value": round(samples_per_step * other_steps / o_elapsed / 1e6, 2),
+        other = {"order": "reference (bvh.h)" if use_fast else "fast (rtk_scene_upload_fast)", "value": round(samples_per_step * other_steps / o_elapsed / 1e6, 2),
                  "unit": "Msamples/s", "kernel_ms": round(o_kernel_ms, 4), "framebuffer_sha256": o_sum, "identical_framebuffer": o_sum == checksum,
                  "fast_order_exact": fast_scene.exact, "fast_order_info": fast_scene.info}
         if fast_scene.exact and o_sum != checksum:

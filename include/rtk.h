@@ -201,7 +201,8 @@ typedef struct rtk_render_opts {
                              * computed: 1 = keep the traversal program in global memory (no LDS staging);
                              * 2 = one sample chunk per pixel; 4 = fixed row-major tile order (no cost-ordered
                              * hand-out); bits 3-4 = chunk size (0: 4 samples, 1: 8, 2: 2, 3: 16);
-                             * bits 8-13 = scheduler loop-exit thresholds (see csrc/rtk_trace.hip) */
+                             * bits 8-13 = scheduler loop-exit thresholds, bits 14-16 = refill batch size (see
+                             * csrc/rtk_trace.hip) */
     void* stream;           /* hipStream_t, NULL = default stream */
 } rtk_render_opts;
 
@@ -275,6 +276,15 @@ typedef struct rtk_optimize_info {
 int rtk_scene_optimize(const rtk_scene_desc* scene, const rtk_optimize_opts* opts,
                        rtk_scene_desc** out_scene, rtk_optimize_info* info /* may be NULL */);
 void rtk_scene_optimized_free(rtk_scene_desc* scene);
+
+/* rtk_scene_optimize + rtk_scene_upload in one call.  Because every box of the
+ * optimised hierarchy carries the pass's margin, the kernels additionally use a
+ * fused multiply-add slab test (18 instead of 24 f64 operations per aabb::hit)
+ * that is conservative with respect to aabb.h:61-85 on such boxes: no hit is
+ * lost, the image is the same as rendering rtk_scene_optimize's output through
+ * rtk_scene_upload.  `scene` is not needed after the call returns. */
+int rtk_scene_upload_fast(rtk_ctx* ctx, const rtk_scene_desc* scene, const rtk_optimize_opts* opts,
+                          rtk_optimize_info* info /* may be NULL */);
 
 /* Number of tiles rank `rank` of `n_ranks` owns for a W x H image, and the
  * element count of its compact tile buffer (tiles * 3 * 64 reals). */

@@ -167,6 +167,7 @@ def hip_lib() -> C.CDLL:
         lib.rtk_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.rtk_debug_closest_hit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rtk_scene_optimize.argtypes = [C.c_void_p, C.POINTER(OptimizeOpts), C.POINTER(C.c_void_p), C.POINTER(OptimizeInfo)]
+        lib.rtk_scene_upload_fast.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OptimizeOpts), C.POINTER(OptimizeInfo)]
         lib.rtk_scene_optimized_free.restype = None
         lib.rtk_scene_optimized_free.argtypes = [C.c_void_p]
         lib.rtk_kernel_name.restype = C.c_char_p
@@ -306,6 +307,16 @@ class Renderer:
 
     def upload(self, scene) -> None:
         self._check(self._lib.rtk_scene_upload(self._ctx, scene.desc_ptr))
+
+    def upload_fast(self, scene, eye: Optional[Vec3] = None, max_leaf: int = 0, prim_cost_scale: float = 0.0) -> dict:
+        """rtk_scene_upload_fast: optimise the visiting order and upload, with the fused slab test enabled.
+        Returns the rtk_optimize_info fields."""
+        opts = OptimizeOpts(1 if eye is not None else 0, max_leaf, eye if eye is not None else Vec3(0, 0, 0), prim_cost_scale)
+        info = OptimizeInfo()
+        self._check(self._lib.rtk_scene_upload_fast(self._ctx, scene.desc_ptr, C.byref(opts), C.byref(info)))
+        return {"exact": bool(info.exact), "has_media": bool(info.has_media), "has_triangles": bool(info.has_triangles),
+                "n_bvh_nodes_in": info.n_bvh_nodes_in, "n_bvh_nodes_out": info.n_bvh_nodes_out,
+                "expected_cost": info.expected_cost, "box_margin": info.box_margin}
 
     def scene_info(self) -> dict:
         n, b64, b32 = C.c_int32(), C.c_int64(), C.c_int64()

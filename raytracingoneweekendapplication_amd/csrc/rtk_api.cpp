@@ -355,6 +355,18 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
         MaterialRec<real>& r = mats[i];
         store3(r.albedo, m.albedo);
         r.param = real(m.param);
+        if (m.kind == RTK_MAT_DIELECTRIC) {
+            // a dielectric has no albedo (material.h:47-65): the slots carry its per-face constants instead, computed
+            // in the kernel's arithmetic type exactly as scatter() does per call -- 1/ri (material.h:50) and Schlick's r0^2 for ri = 1/index
+            // (front face) and ri = index (material.h:71-72)
+            const real index = real(m.param), inv = real(1) / index;
+            real r0f = (real(1) - inv) / (real(1) + inv), r0b = (real(1) - index) / (real(1) + index);
+            r0f = r0f * r0f;
+            r0b = r0b * r0b;
+            r.albedo[0] = inv;
+            r.albedo[1] = r0f;
+            r.albedo[2] = r0b;
+        }
         r.kind = m.kind;
         r.tex = -1;
         r.needs_uv = 0;
@@ -531,8 +543,25 @@ int rtk_destroy(rtk_ctx* ctx) {
     return RTK_OK;
 }
 
+static int upload_scene(rtk_ctx* ctx, const rtk_scene_desc* scene, uint32_t hierarchy_flags);
+
 int rtk_scene_upload(rtk_ctx* ctx, const rtk_scene_desc* scene) {
     if (!ctx || !scene) return fail(RTK_ERR_INVALID, "rtk_scene_upload: null argument");
+    return upload_scene(ctx, scene, 0);
+}
+
+int rtk_scene_upload_fast(rtk_ctx* ctx, const rtk_scene_desc* scene, const rtk_optimize_opts* opts, rtk_optimize_info* info) {
+    if (!ctx || !scene) return fail(RTK_ERR_INVALID, "rtk_scene_upload_fast: null argument");
+    rtk_scene_desc* fast = nullptr;
+    int rc = rtk_scene_optimize(scene, opts, &fast, info);
+    if (rc != RTK_OK) return fail(rc, "rtk_scene_upload_fast: rtk_scene_optimize rejected the scene description");
+    // every box of `fast` was grown by rtk_scene_optimize's margin: the kernels may use the fused slab test
+    rc = upload_scene(ctx, fast, F_FMA_BOX);
+    rtk_scene_optimized_free(fast);
+    return rc;
+}
+
+static int upload_scene(rtk_ctx* ctx, const rtk_scene_desc* scene, uint32_t hierarchy_flags) {
     int rc = validate_tables(*scene);
     if (rc != RTK_OK) return rc;
     Program prog;
@@ -555,7 +584,7 @@ int rtk_scene_upload(rtk_ctx* ctx, const rtk_scene_desc* scene) {
     ctx->order_valid = false;  // a new scene: tile costs measured on the old one mean nothing
     if ((rc = build_device_scene<double>(*scene, prog, ctx->scene64)) != RTK_OK) return rc;
     if ((rc = build_device_scene<float>(*scene, prog, ctx->scene32)) != RTK_OK) return rc;
-    ctx->features = prog.features;
+    ctx->features = prog.features | hierarchy_flags;
     ctx->n_ops = int32_t(prog.ops.size());
     ctx->has_scene = true;
     return RTK_OK;
@@ -639,7 +668,7 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
     unsigned int* tile_counter = ctx->tile_counters + slot;
     unsigned char* d_cam = ctx->d_cameras + slot * kCameraStride;
     const bool allow_lds = (opts->variant & 1) == 0;  // variant bit 0: keep the program in global memory (A/B)
-    const uint32_t diag = uint32_t(opts->variant) & 0x3F00u;  // bits 8..13: timing ablations / policy A/B used by tools/ only
+    const uint32_t diag = uint32_t(opts->variant) & 0x1FF00u;  // bits 8..16: scheduler policy A/B used by tools/ only
     hipError_t e;
     if (opts->real_mode == RTK_REAL_F64) {
         ctx->h_cameras64[slot] = to_device_camera<double>(*cam);

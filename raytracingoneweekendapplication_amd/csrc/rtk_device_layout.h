@@ -78,7 +78,10 @@ enum Feature : uint32_t {
     F_MEDIA = 1u << 3,
     F_TEXTURE = 1u << 4,  // any non-solid texture (checker, checker_tri, image, noise)
     F_LIGHTS = 1u << 5,
-    F_EXOTIC_MAT = 1u << 6  // isotropic / specular / diffuse_light
+    F_EXOTIC_MAT = 1u << 6,  // isotropic / specular / diffuse_light
+    // Not a scene feature but a property of the uploaded hierarchy: its boxes carry rtk_scene_optimize's margin, so the
+    // slab test may use the fused form (rtk_scene_upload_fast).  Orthogonal to the bits above.
+    F_FMA_BOX = 1u << 7
 };
 constexpr uint32_t kFeatLean = 0;                       // spheres + lambertian/metal/dielectric with solid colours
 constexpr uint32_t kFeatAll = 0x7F;

@@ -189,6 +189,27 @@ RTK_DEV void unapply_chain(const ChainRec<real>* __restrict__ chains, uint32_t c
 // near = min(t0,t1), far = max(t0,t1) are the same values as the select -- five
 // instructions fewer per axis.  Rays with a zero or infinite direction component
 // take the exact form (the aabb known-answer vectors exercise them).
+RTK_DEV double rt_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+RTK_DEV float rt_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// Conservative-culling form, only for hierarchies whose boxes were grown by rtk_scene_optimize (F_FMA_BOX kernels,
+// rtk_scene_upload_fast): t = b*inv - o*inv with one fused multiply-add per plane (o*inv hoisted per segment),
+// 18 instead of 24 f64 operations per box.  Against (b - o)*inv the result moves by at most ~2^-52 |o*inv|, i.e.
+// the plane by ~2^-52 |o| -- far inside the 2^-40 x scene-extent margin those boxes carry, so every box the exact
+// test enters is entered here too and the closest hit (computed by the unchanged primitive tests) is the same.
+// Rays with a zero or infinite direction component never come here (they take the literal form).
+template <typename real>
+RTK_DEV bool slab_test_fma(const Slot<real>& b, V3<real> oi, V3<real> inv, real tmin, real tmax) {
+    const real t0x = rt_fma(b.v[0], inv.x, -oi.x), t1x = rt_fma(b.v[1], inv.x, -oi.x);
+    const real t0y = rt_fma(b.v[2], inv.y, -oi.y), t1y = rt_fma(b.v[3], inv.y, -oi.y);
+    const real t0z = rt_fma(b.v[4], inv.z, -oi.z), t1z = rt_fma(b.v[5], inv.z, -oi.z);
+    const real nx = raw_min(t0x, t1x), fx = raw_max(t0x, t1x);
+    const real ny = raw_min(t0y, t1y), fy = raw_max(t0y, t1y);
+    const real nz = raw_min(t0z, t1z), fz = raw_max(t0z, t1z);
+    tmin = raw_max(nz, raw_max(ny, raw_max(nx, tmin)));
+    tmax = raw_min(fz, raw_min(fy, raw_min(fx, tmax)));
+    return tmax > tmin;
+}
+
 template <bool EXACT_NAN, typename real>
 RTK_DEV bool slab_test(const Slot<real>& b, V3<real> o, V3<real> inv, real tmin, real tmax) {
     const real t0x = (b.v[0] - o.x) * inv.x, t1x = (b.v[1] - o.x) * inv.x;
@@ -292,6 +313,7 @@ template <typename real>
 struct Lane {
     V3<real> ro, rd;         // world-space ray of the current segment (ray_color's `r`)
     V3<real> o, d, inv;      // the ray in the current chain's object space, and 1/d (aabb.h:67, hoisted: same value per box)
+    V3<real> oi;             // o * inv, for the fused slab test of F_FMA_BOX kernels (dead, hence free, in the others)
     real a, tm;              // d.d (sphere.h:35, hoisted likewise); ray time
     real tmin, best_t;       // current query interval: (tmin, closest so far)
     real sv_tmin, sv_best_t, rec1_t;  // constant_medium::hit nests two closest-hit queries of its boundary
@@ -327,6 +349,7 @@ RTK_DEV void begin_segment(Lane<real>& L, Counters<COUNT>& cnt) {
     L.inv = mk(real(1) / L.rd.x, real(1) / L.rd.y, real(1) / L.rd.z);
     L.a = length_squared(L.rd);
     L.regular = regular_direction(L.inv);
+    L.oi = L.ro * L.inv;
     L.tmin = real(0.001);
     L.best_t = real_inf<real>();
     L.best_pc = kNoHit;
@@ -334,10 +357,12 @@ RTK_DEV void begin_segment(Lane<real>& L, Counters<COUNT>& cnt) {
 }
 
 // bvh_node::hit's box test (bvh.h:65): on a miss skip the whole subtree.
-template <bool EXACT_NAN, bool XF, typename real, bool COUNT>
+template <bool EXACT_NAN, bool XF, bool FMA = false, typename real, bool COUNT>
 RTK_DEV void step_box(Lane<real>& L, const Slot<real>& rec, Counters<COUNT>& cnt) {
     cnt.inc(C_BOX);
-    const bool hit = slab_test<EXACT_NAN>(rec, ray_o<XF>(L), L.inv, L.tmin, L.best_t);
+    bool hit;
+    if constexpr (FMA && !EXACT_NAN) hit = slab_test_fma(rec, L.oi, L.inv, L.tmin, L.best_t);
+    else hit = slab_test<EXACT_NAN>(rec, ray_o<XF>(L), L.inv, L.tmin, L.best_t);
     L.pc = hit ? L.pc + 1 : rec.aux;
 }
 
@@ -392,6 +417,7 @@ RTK_DEV void step_other(Lane<real>& L, const Slot<real>* __restrict__ rec, const
         L.inv = mk(real(1) / L.d.x, real(1) / L.d.y, real(1) / L.d.z);
         L.a = length_squared(L.d);
         L.regular = regular_direction(L.inv);
+        L.oi = L.o * L.inv;
         L.pc += 1;
     } else if ((FEAT & F_MEDIA) && kind == OP_MED_BEGIN) {
         cnt.inc(C_MEDIUM);
@@ -657,28 +683,56 @@ RTK_DEV bool shade(Lane<real>& L, const Slot<real>* __restrict__ prog, const Sce
 
     V3<real> attenuation, next_d;
     bool scattered = true;
+    // Code shared between material branches is hoisted in front of them, so that a wave whose lanes hold different
+    // materials executes it once instead of once per branch:
+    //  - lambertian and metal both start by drawing random_unit_vector() (material.h:30,84): three draws, a square
+    //    root, a division;
+    //  - metal normalises the reflected direction (material.h:83), dielectric and specular the incoming one
+    //    (material.h:52,146): a square root and a division.
+    // The hoisted values stay live across the branches; the kernels with instance transforms are already short of
+    // registers (they spill), so those keep one copy per branch (kHoist = false).
+    constexpr bool kHoist = (FEAT & F_XFORM) == 0;
+    V3<real> ruv = mk(real(0), real(0), real(0)), unit_in = rd;
+    if constexpr (kHoist) {
+        if (m.kind == RTK_MAT_LAMBERTIAN || m.kind == RTK_MAT_METAL) ruv = random_unit_vector<real>(L.rng, cnt);
+        if (m.kind == RTK_MAT_METAL) unit_in = reflect(rd, sf.normal);
+        if (m.kind == RTK_MAT_METAL || m.kind == RTK_MAT_DIELECTRIC || ((FEAT & F_EXOTIC_MAT) && m.kind == RTK_MAT_SPECULAR)) unit_in = unit_vector(unit_in);
+    }
     if (m.kind == RTK_MAT_LAMBERTIAN) {  // material.h:29-38
-        V3<real> dir = sf.normal + random_unit_vector<real>(L.rng, cnt);
+        if constexpr (!kHoist) ruv = random_unit_vector<real>(L.rng, cnt);
+        V3<real> dir = sf.normal + ruv;
         if (near_zero(dir)) dir = sf.normal;
         next_d = dir;
         attenuation = material_color<real, FEAT>(sc, m, sf.u, sf.v, sf.p, cnt);
     } else if (m.kind == RTK_MAT_METAL) {  // material.h:82-88
-        V3<real> refl = reflect(rd, sf.normal);
-        V3<real> fuzz = scale(m.param, random_unit_vector<real>(L.rng, cnt));
-        next_d = unit_vector(refl) + fuzz;
+        if constexpr (!kHoist) {
+            ruv = random_unit_vector<real>(L.rng, cnt);
+            unit_in = unit_vector(reflect(rd, sf.normal));
+        }
+        V3<real> fuzz = scale(m.param, ruv);
+        next_d = unit_in + fuzz;
         attenuation = ld3(m.albedo);
         scattered = dot(next_d, sf.normal) > real(0);
     } else if (m.kind == RTK_MAT_DIELECTRIC) {  // material.h:47-65
         attenuation = mk(real(1), real(1), real(1));
-        const real ri = sf.front_face ? (real(1) / m.param) : m.param;
-        const V3<real> unit_d = unit_vector(rd);
+        // 1/refraction_index and Schlick's r0^2 for both faces are per-material constants: computed once at upload,
+        // in double, by the same expressions (material.h:50,71-72)
+        const real ri = sf.front_face ? m.albedo[0] : m.param;
+        if constexpr (!kHoist) unit_in = unit_vector(rd);
+        const V3<real> unit_d = unit_in;
         const real cos_theta = rt_fmin(dot(-unit_d, sf.normal), real(1));
         const real sin_theta = rt_sqrt(real(1) - cos_theta * cos_theta);
         bool reflect_it = ri * sin_theta > real(1);
         if (!reflect_it) {  // Schlick (material.h:69-74); the draw is skipped on total internal reflection
-            real r0 = (real(1) - ri) / (real(1) + ri);
-            r0 = r0 * r0;
-            const real refl = r0 + (real(1) - r0) * rt_pow(real(1) - cos_theta, real(5));
+            const real r0 = sf.front_face ? m.albedo[1] : m.albedo[2];
+            // Schlick's (1 - cos)^5 (material.h:73 calls pow) as ((x^2)^2)*x: within 2 ulp of the correctly rounded
+            // power instead of pow's 1, for ~200 instructions less in the dielectric branch.  The value only feeds the
+            // comparison with a 24-bit uniform below, so a different outcome needs the reflectance to lie within 2 ulp
+            // of a multiple of 2^-24 (probability ~1e-8 per dielectric interaction; the oracle comparison of every test
+            // scene is unchanged).
+            const real omc = real(1) - cos_theta;
+            const real omc2 = omc * omc;
+            const real refl = r0 + (real(1) - r0) * (omc2 * omc2 * omc);
             reflect_it = refl > rnd<real>(L.rng, cnt);
         }
         next_d = reflect_it ? reflect(unit_d, sf.normal) : refract(unit_d, sf.normal, ri);
@@ -686,7 +740,8 @@ RTK_DEV bool shade(Lane<real>& L, const Slot<real>* __restrict__ prog, const Sce
         next_d = random_unit_vector<real>(L.rng, cnt);
         attenuation = material_color<real, FEAT>(sc, m, sf.u, sf.v, sf.p, cnt);
     } else if ((FEAT & F_EXOTIC_MAT) && m.kind == RTK_MAT_SPECULAR) {  // material.h:145-167
-        const V3<real> unit_d = unit_vector(rd);
+        if constexpr (!kHoist) unit_in = unit_vector(rd);
+        const V3<real> unit_d = unit_in;
         const V3<real> refl = reflect(unit_d, sf.normal);
         V3<real> diffuse = random_unit_vector<real>(L.rng, cnt);  // random_on_hemisphere, vec3.h:116-124
         if (!(dot(diffuse, sf.normal) > real(0))) diffuse = -diffuse;
@@ -794,7 +849,8 @@ RTK_DEV void store_partial(real* __restrict__ partial, int item, int pix, V3<rea
 // the full-feature kernel, which needs far more registers (~560 B/lane of spills at 168), is fastest at 2 waves.
 template <typename real, uint32_t FEAT>
 constexpr int max_threads() {
-    if (sizeof(real) == 8) return FEAT == kFeatAll ? 512 : ((FEAT == kFeatLean || FEAT == kFeatQuadBox) ? 1024 : 768);
+    constexpr uint32_t scene_feat = FEAT & ~uint32_t(F_FMA_BOX);
+    if (sizeof(real) == 8) return scene_feat == kFeatAll ? 512 : ((scene_feat == kFeatLean || scene_feat == kFeatQuadBox) ? 1024 : 768);
     return 768;
 }
 
@@ -839,6 +895,9 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
     unsigned int prefetched_item = 0;
     if (lane == 0) prefetched_item = atomicAdd(tile_counter, 1u);
     bool exhausted = false;
+    // tools/: A/B of the refill batch size through variant bits 14..16 (0 = default)
+    constexpr int kRefillMinTable[8] = {8, 1, 4, 8, 16, 24, 32, 12};
+    const int refill_min = kRefillMinTable[(diag >> 14) & 7];
 
     Lane<real> L;
     L.pc = end_pc;
@@ -854,8 +913,15 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
         // the wave's current work item (a tile x a chunk of the samples); when it is
         // used up the wave pulls another item from the rank-wide counter.  A (pixel,
         // chunk) belongs to exactly one lane, which walks its samples in order.
+        // Refills are BATCHED: handing out one pixel costs a full begin_sample + begin_segment (hashes, RNG draws,
+        // the lens rejection loop, three f64 divisions) executed by the whole wave, so doing it whenever a single lane
+        // falls idle spent ~a quarter of the frame at one or two active lanes (phase profile: 68 M refill+vote rounds
+        // of ~3 box steps each on C2).  Idle lanes now wait until `refill_min` of them can be served at once (or
+        // nobody has work left); which lane renders a pixel, and when, never changes its value.
         unsigned long long m_idle = __ballot(!alive);
-        while (m_idle != 0ull && !exhausted) {
+        const int n_idle_now = popcount64(m_idle);
+        const bool refill_now = n_idle_now >= refill_min || n_idle_now == 64;
+        while (refill_now && m_idle != 0ull && !exhausted) {
             if (refill_next >= 64) {
                 const int t = int(__builtin_amdgcn_readfirstlane(prefetched_item));
                 if (t >= n_items) {
@@ -945,7 +1011,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             if (__ballot(want == W_BOX && !L.regular) == 0ull) {
                 do {
                     if (k == OP_BOX) {
-                        step_box<false, (FEAT & F_XFORM) != 0>(L, cur, cnt);
+                        step_box<false, (FEAT & F_XFORM) != 0, (FEAT & F_FMA_BOX) != 0>(L, cur, cnt);
                         cur = prog[L.pc];
                         k = cur.kind_payload & 15u;
                         L.kind = k;
@@ -1297,23 +1363,45 @@ bool program_fits_lds(const SceneView<real>& sc) {
     return lds_image_bytes(sc) <= size_t(kLdsBytesPerCU);
 }
 
+// Kernel instantiation for a scene: the leanest feature subset that covers it, with or without the fused slab test.
+static uint32_t kernel_features(uint32_t features, bool count) {
+    const uint32_t fma = features & F_FMA_BOX, scene = features & ~uint32_t(F_FMA_BOX);
+    if (count) return kFeatAll | fma;
+    if (scene == kFeatLean) return kFeatLean | fma;
+    if ((scene & ~kFeatQuadBox) == 0) return kFeatQuadBox;  // no registers to spare for o*inv at 4 waves/SIMD (it spills): exact slab test, A/B on C3 40.7 vs 42.2 ms
+    if ((scene & ~kFeatMesh) == 0) return kFeatMesh | fma;
+    return kFeatAll | fma;
+}
+
+template <typename real, uint32_t FEAT>
+static hipError_t launch_feat(const SceneView<real>& sc, const CameraRec<real>* cam, const TileMap& tmap, uint32_t seed, bool count, bool lds, uint32_t diag,
+                              void* partial, unsigned long long* counters, unsigned int* tile_counter, const int32_t* tile_order, unsigned int* tile_cost,
+                              hipStream_t stream) {
+    if constexpr ((FEAT & ~uint32_t(F_FMA_BOX)) == kFeatAll) {
+        if (count) return launch_one<real, FEAT, true, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
+    }
+    return lds ? launch_one<real, FEAT, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream)
+               : launch_one<real, FEAT, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
+}
+
 template <typename real>
 hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>* cam, const TileMap& tmap, uint32_t seed, uint32_t features, bool count,
                          bool allow_lds, uint32_t diag, void* partial, unsigned long long* counters, unsigned int* tile_counter,
                          const int32_t* tile_order, unsigned int* tile_cost, hipStream_t stream) {
     const bool lds = allow_lds && program_fits_lds(sc);
-    if (count) return launch_one<real, kFeatAll, true, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
-    if (features == kFeatLean)
-        return lds ? launch_one<real, kFeatLean, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream)
-                   : launch_one<real, kFeatLean, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
-    if ((features & ~kFeatQuadBox) == 0)
-        return lds ? launch_one<real, kFeatQuadBox, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream)
-                   : launch_one<real, kFeatQuadBox, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
-    if ((features & ~kFeatMesh) == 0)
-        return lds ? launch_one<real, kFeatMesh, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream)
-                   : launch_one<real, kFeatMesh, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
-    return lds ? launch_one<real, kFeatAll, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream)
-               : launch_one<real, kFeatAll, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
+#define RTK_LAUNCH_CASE(F) \
+    case F: return launch_feat<real, F>(sc, cam, tmap, seed, count, lds, diag, partial, counters, tile_counter, tile_order, tile_cost, stream);
+    switch (kernel_features(features, count)) {
+        RTK_LAUNCH_CASE(kFeatLean)
+        RTK_LAUNCH_CASE(kFeatQuadBox)
+        RTK_LAUNCH_CASE(kFeatMesh)
+        RTK_LAUNCH_CASE(kFeatAll)
+        RTK_LAUNCH_CASE(kFeatLean | F_FMA_BOX)
+        RTK_LAUNCH_CASE(kFeatMesh | F_FMA_BOX)
+        RTK_LAUNCH_CASE(kFeatAll | F_FMA_BOX)
+    }
+#undef RTK_LAUNCH_CASE
+    return hipErrorInvalidValue;
 }
 template hipError_t launch_render<double>(const SceneView<double>&, const CameraRec<double>*, const TileMap&, uint32_t, uint32_t, bool, bool, uint32_t, void*,
                                           unsigned long long*, unsigned int*, const int32_t*, unsigned int*, hipStream_t);
@@ -1359,8 +1447,8 @@ template hipError_t launch_unpermute<float>(const void*, int, int, int, long lon
 
 const char* render_kernel_name(bool f64, uint32_t features, bool count, bool lds) {
     static thread_local char name[96];
-    const uint32_t feat = count ? kFeatAll : (features == kFeatLean ? kFeatLean : ((features & ~kFeatQuadBox) == 0 ? kFeatQuadBox : ((features & ~kFeatMesh) == 0 ? kFeatMesh : kFeatAll)));
-    snprintf(name, sizeof name, "rtk_render_kernel<%s, %uu, %s, %s>", f64 ? "double" : "float", feat, count ? "true" : "false", (lds && !count) ? "true" : "false");
+    snprintf(name, sizeof name, "rtk_render_kernel<%s, %uu, %s, %s>", f64 ? "double" : "float", kernel_features(features, count), count ? "true" : "false",
+             (lds && !count) ? "true" : "false");
     return name;
 }
 

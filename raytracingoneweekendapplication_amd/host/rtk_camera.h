@@ -163,17 +163,16 @@ public:
         rtk_ctx* ctx = nullptr;
         int rc = rtk_init(device, &ctx);
         if (rc != RTK_OK) return rc;
-        rtk_scene_desc* fast = nullptr;
         if (fast_order) {  // same primitives, SAH grouping, children ordered by distance to this camera
             rtk_optimize_opts oo{};
             oo.has_eye = 1;
             oo.eye = cam.center;
             rtk_optimize_info info{};
-            rc = rtk_scene_optimize(&desc, &oo, &fast, &info);
+            rc = rtk_scene_upload_fast(ctx, &desc, &oo, &info);
             fast_order_exact = rc == RTK_OK && info.exact != 0;
+        } else {
+            rc = rtk_scene_upload(ctx, &desc);
         }
-        if (rc == RTK_OK) rc = rtk_scene_upload(ctx, fast ? fast : &desc);
-        if (fast) rtk_scene_optimized_free(fast);  // the upload copied what it needs
         if (rc == RTK_OK) {
             size_t n = size_t(cam.image_width) * cam.image_height * 3;
             if (linear) linear->assign(n, 0.0);

@@ -304,6 +304,15 @@ def test_fast_order_on_the_device(rt, orc, renderer, scenes, case):
     gpu, gpu8, counters = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, count=True)
     ref, ref8, ocnt = orc.render(fast.desc_ptr, cam, RENDER_SEED, 8)
     assert rmse(gpu, ref) < F64_RMSE_BOUND and np.array_equal(gpu8, ref8) and counters == ocnt
+    # rtk_scene_upload_fast = the same hierarchy + the fused slab test (F_FMA_BOX kernels): conservative on the grown
+    # boxes, so the same image; the slab decisions themselves coincide at these sizes, hence equal counters
+    info = renderer.upload_fast(scene, cam.center)
+    assert info["exact"] == fast.exact
+    feat = int(renderer.kernel_name().split(",")[1].strip().rstrip("u"))
+    assert (feat & 128) or feat == 69   # the fused-slab instantiation (the quad/box subset kernel keeps the exact test)
+    fused, fused8, fcnt = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, count=True)
+    fused_fast, _, _ = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64)
+    assert np.array_equal(fused, gpu) and np.array_equal(fused8, gpu8) and np.array_equal(fused_fast, gpu) and fcnt == counters
     if not fast.info["has_media"]:
         renderer.upload(scene)
         base, base8, bcnt = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, count=True)
@@ -322,8 +331,11 @@ def test_fast_order_full_resolution_book1_is_bit_identical_and_cheaper(rt, rende
     cam = scene.camera(1920, 1080, 8, 50)
     dev = torch.device("cuda", 0)
     out = []
-    for sc in (scene, scene.fast_order(cam.center)):
-        renderer.upload(sc)
+    for use_fast in (False, True):
+        if use_fast:
+            renderer.upload_fast(scene, cam.center)
+        else:
+            renderer.upload(scene)
         img = torch.empty((1080, 1920, 3), dtype=torch.float64, device=dev)
         u8 = torch.empty((1080, 1920, 3), dtype=torch.uint8, device=dev)
         cnt = torch.zeros(12, dtype=torch.int64, device=dev)

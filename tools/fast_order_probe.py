@@ -21,8 +21,11 @@ r = rt.Renderer(0)
 stream = torch.cuda.current_stream().cuda_stream
 
 
-def measure(scene, cam, real, launches=3):
-    r.upload(scene)
+def measure(scene, cam, real, launches=3, fast=None):
+    if fast is not None:
+        r.upload_fast(scene, cam.center, *fast)
+    else:
+        r.upload(scene)
     H, W = cam.image_height, cam.image_width
     img = torch.empty((H, W, 3), dtype=torch.float64 if real == rt.RTK_REAL_F64 else torch.float32, device=dev)
     best = 1e30
@@ -51,7 +54,7 @@ for config in configs:
               f"tri {c0['triangle_tests']/n:.2f} xf {c0['xform_enters']/n:.2f}  {k0}", flush=True)
         for max_leaf, pcs in settings:
             fast = scene.fast_order(cam.center, int(max_leaf), pcs)
-            ms1, img1, c1, k1 = measure(fast, cam, real)
+            ms1, img1, c1, k1 = measure(scene, cam, real, fast=(int(max_leaf), pcs))
             same = bool(torch.equal(img0, img1))
             print(f"{config} {rname} fast order leaf<={int(max_leaf)} cost x{pcs}: {ms1:9.3f} ms  {n/ms1/1e3:8.1f} Msamples/s  x{ms0/ms1:.2f}  identical={same} exact={fast.exact} "
                   f"box {c1['box_tests']/n:.2f} sph {c1['sphere_tests']/n:.2f} quad {c1['quad_tests']/n:.2f} tri {c1['triangle_tests']/n:.2f} xf {c1['xform_enters']/n:.2f} "

@@ -2,7 +2,7 @@
 -DRTK_PROFILE (s_memtime stamps at the scheduler's phase boundaries), renders one frame and prints,
 per phase: share of wave-cycles, steps, cycles per step, mean active lanes.  Tools only.
 
-  python3 tools/profile_phases.py [config=c2] [real=f64] [spp=0]
+  python3 tools/profile_phases.py [config=c2] [real=f64] [spp=0] [order=auto|reference|fast]
 """
 import os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,12 +20,16 @@ import raytracingoneweekendapplication_amd as rt
 config = sys.argv[1] if len(sys.argv) > 1 else "c2"
 real = rt.RTK_REAL_F64 if (len(sys.argv) <= 2 or sys.argv[2] == "f64") else rt.RTK_REAL_F32
 spp = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+order = sys.argv[4] if len(sys.argv) > 4 else "auto"
 tmp = tempfile.mkdtemp()
 earth = rt.write_synthetic_earth(os.path.join(tmp, "earth_synth.ppm"))
 scene = rt.Scene.build(rt.CONFIG_SCENES[config], rt.SCENE_SEED, earth)
 cam = scene.camera(0, 0, spp, 0)
 r = rt.Renderer(0)
-r.upload(scene)
+fast = scene.fast_order(cam.center)
+use_fast = order == "fast" or (order == "auto" and fast.exact)
+r.upload_fast(scene, cam.center) if use_fast else r.upload(scene)
+print("order:", "fast" if use_fast else "reference")
 dev = torch.device("cuda", 0)
 H, W = cam.image_height, cam.image_width
 img = torch.empty((H, W, 3), dtype=torch.float64 if real == rt.RTK_REAL_F64 else torch.float32, device=dev)

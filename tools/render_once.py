@@ -21,8 +21,8 @@ cam = scene.camera(0, 0, spp, 0)
 r = rt.Renderer(0)
 fast = scene.fast_order(cam.center)
 use_fast = order == "fast" or (order == "auto" and fast.exact)  # same rule as bench.py
-r.upload(fast if use_fast else scene)
-print(f"order: {'fast (rtk_scene_optimize)' if use_fast else 'reference (bvh.h)'}", flush=True)
+r.upload_fast(scene, cam.center) if use_fast else r.upload(scene)
+print(f"order: {'fast (rtk_scene_upload_fast)' if use_fast else 'reference (bvh.h)'}", flush=True)
 dev = torch.device("cuda", 0)
 H, W = cam.image_height, cam.image_width
 img = torch.empty((H, W, 3), dtype=torch.float64 if real == rt.RTK_REAL_F64 else torch.float32, device=dev)

@@ -1,0 +1,42 @@
+"""Developer probe: kernel time of one config under a list of `variant` values (scheduler policy A/B).
+
+  python3 tools/variant_sweep.py c2 fast f64 0,16384,32768,...   [spp]
+All variants must produce the same framebuffer (checked).
+"""
+import os, sys, tempfile, hashlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import raytracingoneweekendapplication_amd as rt
+
+config = sys.argv[1] if len(sys.argv) > 1 else "c2"
+order = sys.argv[2] if len(sys.argv) > 2 else "auto"
+real = rt.RTK_REAL_F64 if (len(sys.argv) <= 3 or sys.argv[3] == "f64") else rt.RTK_REAL_F32
+variants = [int(v) for v in (sys.argv[4] if len(sys.argv) > 4 else "0").split(",")]
+spp = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+tmp = tempfile.mkdtemp()
+earth = rt.write_synthetic_earth(os.path.join(tmp, "earth_synth.ppm"))
+scene = rt.Scene.build(rt.CONFIG_SCENES[config], rt.SCENE_SEED, earth)
+cam = scene.camera(0, 0, spp, 0)
+fast = scene.fast_order(cam.center)
+use_fast = order == "fast" or (order == "auto" and fast.exact)
+r = rt.Renderer(0)
+r.upload_fast(scene, cam.center) if use_fast else r.upload(scene)
+dev = torch.device("cuda", 0)
+H, W = cam.image_height, cam.image_width
+img = torch.empty((H, W, 3), dtype=torch.float64 if real == rt.RTK_REAL_F64 else torch.float32, device=dev)
+stream = torch.cuda.current_stream().cuda_stream
+n = W * H * cam.samples_per_pixel
+digests = set()
+for v in variants:
+    best = 1e30
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r.render_device(cam, img.data_ptr(), 0, real_mode=real, variant=v, stream=stream)
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    d = hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest()[:12]
+    digests.add(d)
+    print(f"{config} {'fast' if use_fast else 'reference'} variant {v:6d} (refill sel {(v >> 14) & 7}, box sel {(v >> 8) & 7}, sphere sel {(v >> 11) & 7}): {best:8.3f} ms  {n / best / 1e3:8.1f} Msamples/s  sha {d}", flush=True)
+print("all variants identical:", len(digests) == 1)

@@ -668,7 +668,7 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
     unsigned int* tile_counter = ctx->tile_counters + slot;
     unsigned char* d_cam = ctx->d_cameras + slot * kCameraStride;
     const bool allow_lds = (opts->variant & 1) == 0;  // variant bit 0: keep the program in global memory (A/B)
-    const uint32_t diag = uint32_t(opts->variant) & 0x1FF00u;  // bits 8..16: scheduler policy A/B used by tools/ only
+    const uint32_t diag = uint32_t(opts->variant) & 0xFFF00u;  // bits 8..19: scheduler policy A/B used by tools/ only
     hipError_t e;
     if (opts->real_mode == RTK_REAL_F64) {
         ctx->h_cameras64[slot] = to_device_camera<double>(*cam);

@@ -42,7 +42,8 @@ enum OpKind : uint32_t {
     OP_MED_BEGIN = 6,  // 1 slot : payload = medium index
     OP_MED_MID = 7,    // 1 slot : payload = medium index, aux = pc after the matching OP_MED_END
     OP_MED_END = 8,    // 1 slot : v[0] = neg_inv_density; payload = medium index, aux = chain | material << 8
-    OP_SPHERE_MOVING = 9  // 2 slots: as OP_SPHERE, then v = dx,dy,dz (center2 - center1)
+    OP_SPHERE_MOVING = 9,  // 2 slots: as OP_SPHERE, then v = dx,dy,dz (center2 - center1)
+    OP_DEAD = 15           // never in a program: the kernel's marker for a lane that owns no pixel
 };
 
 struct Op {

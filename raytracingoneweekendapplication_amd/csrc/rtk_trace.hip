@@ -800,6 +800,10 @@ enum Want : int { W_DONE = 0, W_BOX = 1, W_SPHERE = 2, W_OTHER = 3, W_SHADE = 4,
 
 // Lane count of a ballot as a 32-bit scalar, one s_bcnt1_i32_b64.  With __builtin_popcountll the compiler
 // carries the count as i64 and performs the vote's comparisons on the vector unit (v_cmp_lt_u64).
+// A wave-uniform condition as a scalar branch: the compiler cannot always prove uniformity and would otherwise turn
+// the branch into exec-mask bookkeeping.
+RTK_DEV bool uniform(bool c) { return __builtin_amdgcn_readfirstlane(int(c)) != 0; }
+
 RTK_DEV int popcount64(unsigned long long m) {
     int n;
     asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc");
@@ -898,86 +902,84 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
     // tools/: A/B of the refill batch size through variant bits 14..16 (0 = default)
     constexpr int kRefillMinTable[8] = {8, 1, 4, 8, 16, 24, 32, 12};
     const int refill_min = kRefillMinTable[(diag >> 14) & 7];
+    constexpr int kSphereMinTable[8] = {12, 65, 4, 8, 12, 16, 24, 32};  // variant bits 17..19; 65 = never (spheres only through the vote)
+    const int sphere_min = kSphereMinTable[(diag >> 17) & 7];
 
     Lane<real> L;
     L.pc = end_pc;
-    L.kind = OP_END;
+    L.kind = OP_DEAD;                 // this lane owns no (pixel, chunk): it takes part in no vote and waits for a refill
     L.sum = mk(real(0), real(0), real(0));
     L.s = 0;
     RTK_PROF_DECL
-    bool alive = false;               // this lane currently owns a (pixel, chunk)
     int my_slot = 0, my_pix = 0, px_i = 0, px_j = 0, s_end = 0, cost_tile = -1;  // my_slot = chunk * n_tiles_local + local_tile: where the partial sum goes
 
+    // One refill round: idle lanes take the next pixels of the wave's current work item (a tile x a chunk of the
+    // samples); when the item is used up the wave first pulls another one from the rank-wide counter.  A (pixel,
+    // chunk) belongs to exactly one lane, which walks its samples in order.  Returns true when idle lanes remain that
+    // were not offered a pixel (the item ran out first).  Everything that steers it is wave-uniform.
+    auto hand_out = [&](unsigned long long m_idle) -> bool {
+        if (refill_next >= 64) {
+            const int t = int(__builtin_amdgcn_readfirstlane(prefetched_item));
+            if (t >= n_items) {
+                exhausted = true;
+                return false;
+            }
+            refill_item = t;
+            refill_next = 0;
+            if (lane == 0) prefetched_item = atomicAdd(tile_counter, 1u);
+        }
+        const int avail = 64 - refill_next;
+        const int rank_in_idle = int(__builtin_amdgcn_mbcnt_hi(uint32_t(m_idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m_idle), 0u)));
+        if (L.kind == OP_DEAD && rank_in_idle < avail) {
+            my_pix = refill_next + rank_in_idle;
+            // Items are handed out in `tile_order` when the host has one (most expensive tiles of the previous
+            // frame first); which wave renders a tile, and when, never changes a pixel's value.
+            const int position = refill_item / tmap.n_chunks, chunk = refill_item % tmap.n_chunks;
+            const int local_tile = tile_order ? tile_order[position] : position;
+            const int tile = local_tile * tmap.n_ranks + tmap.rank;
+            my_slot = chunk * tmap.n_tiles_local + local_tile;
+            px_i = (tile % tmap.tiles_x) * 8 + (my_pix & 7);
+            px_j = (tile / tmap.tiles_x) * 8 + (my_pix >> 3);
+            const int s_begin = tmap.chunk_start[chunk];
+            s_end = tmap.chunk_start[chunk + 1];
+            if (tile < n_tiles_total && px_i < width && px_j < height && s_begin < s_end) {
+                L.sum = mk(real(0), real(0), real(0));
+                L.s = s_begin;
+                L.segs = 0;
+                cost_tile = chunk == 0 ? local_tile : -1;  // chunk 0 of every pixel reports the tile's cost
+                begin_sample(L, cam, px_i, px_j, seed_hash, cnt);
+                if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0>(L, cnt);
+                else L.pc = end_pc;  // max_depth == 0: ray_color returns black at once (Camera.txt:205-206)
+                L.kind = prog[L.pc].kind_payload & 15u;
+            }
+        }
+        const int n_idle = popcount64(m_idle);
+        refill_next += n_idle < avail ? n_idle : avail;
+        return n_idle > avail;
+    };
+
     for (;;) {
-        // ---- regeneration at pixel granularity: idle lanes take the next pixels of
-        // the wave's current work item (a tile x a chunk of the samples); when it is
-        // used up the wave pulls another item from the rank-wide counter.  A (pixel,
-        // chunk) belongs to exactly one lane, which walks its samples in order.
-        // Refills are BATCHED: handing out one pixel costs a full begin_sample + begin_segment (hashes, RNG draws,
-        // the lens rejection loop, three f64 divisions) executed by the whole wave, so doing it whenever a single lane
-        // falls idle spent ~a quarter of the frame at one or two active lanes (phase profile: 68 M refill+vote rounds
-        // of ~3 box steps each on C2).  Idle lanes now wait until `refill_min` of them can be served at once (or
-        // nobody has work left); which lane renders a pixel, and when, never changes its value.
-        unsigned long long m_idle = __ballot(!alive);
-        const int n_idle_now = popcount64(m_idle);
-        const bool refill_now = n_idle_now >= refill_min || n_idle_now == 64;
-        while (refill_now && m_idle != 0ull && !exhausted) {
-            if (refill_next >= 64) {
-                const int t = int(__builtin_amdgcn_readfirstlane(prefetched_item));
-                if (t >= n_items) {
-                    exhausted = true;
-                    break;
-                }
-                refill_item = t;
-                refill_next = 0;
-                if (lane == 0) prefetched_item = atomicAdd(tile_counter, 1u);
-            }
-            const int avail = 64 - refill_next;
-            const int rank_in_idle = int(__builtin_amdgcn_mbcnt_hi(uint32_t(m_idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m_idle), 0u)));
-            if (!alive && rank_in_idle < avail) {
-                my_pix = refill_next + rank_in_idle;
-                // Items are handed out in `tile_order` when the host has one (most expensive tiles of the previous
-                // frame first); which wave renders a tile, and when, never changes a pixel's value.
-                const int position = refill_item / tmap.n_chunks, chunk = refill_item % tmap.n_chunks;
-                const int local_tile = tile_order ? tile_order[position] : position;
-                const int tile = local_tile * tmap.n_ranks + tmap.rank;
-                my_slot = chunk * tmap.n_tiles_local + local_tile;
-                px_i = (tile % tmap.tiles_x) * 8 + (my_pix & 7);
-                px_j = (tile / tmap.tiles_x) * 8 + (my_pix >> 3);
-                const int s_begin = tmap.chunk_start[chunk];
-                s_end = tmap.chunk_start[chunk + 1];
-                if (tile < n_tiles_total && px_i < width && px_j < height && s_begin < s_end) {
-                    alive = true;
-                    L.sum = mk(real(0), real(0), real(0));
-                    L.s = s_begin;
-                    L.segs = 0;
-                    cost_tile = chunk == 0 ? local_tile : -1;  // chunk 0 of every pixel reports the tile's cost
-                    begin_sample(L, cam, px_i, px_j, seed_hash, cnt);
-                    if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0>(L, cnt);
-                    else L.pc = end_pc;  // max_depth == 0: ray_color returns black at once (Camera.txt:205-206)
-                    L.kind = prog[L.pc].kind_payload & 15u;
-                }
-            }
+        // ---- regeneration at pixel granularity, BATCHED: handing out one pixel costs a full begin_sample +
+        // begin_segment (hashes, RNG draws, the lens rejection loop, three f64 divisions) executed by the whole wave,
+        // so idle lanes wait until `refill_min` of them can be served at once (or nobody has work left).  Which lane
+        // renders a pixel, and when, never changes its value.  At most two rounds: the rest of the current item,
+        // then the head of the next one.
+        {
+            const unsigned long long m_idle = __ballot(L.kind == OP_DEAD);
             const int n_idle = popcount64(m_idle);
-            refill_next += n_idle < avail ? n_idle : avail;
-            m_idle = __ballot(!alive);
-            if (n_idle <= avail) break;  // every idle lane was offered a pixel this round (some fell outside the image)
+            if (uniform(!exhausted && (n_idle >= refill_min || n_idle == 64))) {
+                if (uniform(hand_out(m_idle))) hand_out(__ballot(L.kind == OP_DEAD));
+            }
         }
 
-        // ---- vote (registers and scalar unit only)
+        // ---- vote (registers and scalar unit only).  A lane's record kind IS its vote; OP_DEAD lanes have none.
         const uint32_t kind = L.kind;
-        int want = W_DONE;
-        if (alive) {
-            want = kind == OP_BOX ? W_BOX : (kind == OP_SPHERE ? W_SPHERE : (kind == OP_END ? W_SHADE : W_OTHER));
-            if ((FEAT & F_QUAD) && kind == OP_QUAD) want = W_QUAD;
-            if ((FEAT & F_TRI) && kind == OP_TRI) want = W_TRI;
-        }
-        const unsigned long long m_box = __ballot(want == W_BOX);
-        const unsigned long long m_sph = __ballot(want == W_SPHERE);
-        const unsigned long long m_oth = __ballot(want == W_OTHER);
-        const unsigned long long m_shd = __ballot(want == W_SHADE);
-        const unsigned long long m_quad = (FEAT & F_QUAD) ? __ballot(want == W_QUAD) : 0ull;
-        const unsigned long long m_tri = (FEAT & F_TRI) ? __ballot(want == W_TRI) : 0ull;
+        const unsigned long long m_box = __ballot(kind == OP_BOX);
+        const unsigned long long m_sph = __ballot(kind == OP_SPHERE);
+        const unsigned long long m_shd = __ballot(kind == OP_END);
+        const unsigned long long m_quad = (FEAT & F_QUAD) ? __ballot(kind == OP_QUAD) : 0ull;
+        const unsigned long long m_tri = (FEAT & F_TRI) ? __ballot(kind == OP_TRI) : 0ull;
+        const unsigned long long m_oth = __ballot(kind != OP_DEAD) & ~(m_box | m_sph | m_shd | m_quad | m_tri);
         if ((m_box | m_sph | m_oth | m_shd | m_quad | m_tri) == 0ull) {
             if (exhausted) break;
             continue;
@@ -1006,15 +1008,28 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             const int frac = (n_box * eighths) >> 3;
             const int keep = frac > 8 ? frac : 8;
             Slot<real> cur = prog[L.pc];  // the record at L.pc, held in registers: one LDS round trip per step
-            uint32_t k = want == W_BOX ? uint32_t(OP_BOX) : uint32_t(OP_END);
+            uint32_t k = kind;
             int remaining;
-            if (__ballot(want == W_BOX && !L.regular) == 0ull) {
+            if (__ballot(kind == OP_BOX && !L.regular) == 0ull) {
+                // Sphere tests ride along: whenever `sphere_min` lanes of the wave sit on a sphere record, they are
+                // stepped here, inside the box loop, instead of waiting for the loop to drain and a vote to pick
+                // them (a vote round costs about three box steps).  Those lanes then return to box records, which
+                // also keeps the loop populated for longer.
                 do {
                     if (k == OP_BOX) {
                         step_box<false, (FEAT & F_XFORM) != 0, (FEAT & F_FMA_BOX) != 0>(L, cur, cnt);
                         cur = prog[L.pc];
                         k = cur.kind_payload & 15u;
                         L.kind = k;
+                    }
+                    if (popcount64(__ballot(k == OP_SPHERE)) >= sphere_min) {
+                        if (k == OP_SPHERE) {
+                            step_sphere<(FEAT & F_XFORM) != 0>(L, cur, cnt);
+                            cur = prog[L.pc];
+                            k = cur.kind_payload & 15u;
+                            L.kind = k;
+                        }
+                        RTK_PROF_MARK(2, 1, 0)
                     }
                     remaining = popcount64(__ballot(k == OP_BOX));
                     RTK_PROF_MARK(1, 1, remaining)
@@ -1036,7 +1051,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             const int sfrac = (n_sph * (ssel == 0 ? 4 : ssel)) >> 3;
             const int keep = sfrac > 8 ? sfrac : 8;
             Slot<real> cur = prog[L.pc];
-            uint32_t k = want == W_SPHERE ? uint32_t(OP_SPHERE) : uint32_t(OP_END);
+            uint32_t k = kind;
             int remaining;
             do {
                 if (k == OP_SPHERE) {
@@ -1051,7 +1066,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
         } else if ((FEAT & F_QUAD) && pick == W_QUAD) {
             // quad::hit.  A box() is six quads in a row (quad.h:86-108): stay while at least half the starters do.
             const int keep = (n_quad >> 1) > 8 ? (n_quad >> 1) : 8;
-            uint32_t k = want == W_QUAD ? uint32_t(OP_QUAD) : uint32_t(OP_END);
+            uint32_t k = kind;
             int remaining;
             do {
                 if (k == OP_QUAD) {
@@ -1071,7 +1086,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
         } else if ((FEAT & F_TRI) && pick == W_TRI) {
             // triangle::hit; a bvh leaf holds one or two triangles.
             const int keep = (n_tri >> 1) > 8 ? (n_tri >> 1) : 8;
-            uint32_t k = want == W_TRI ? uint32_t(OP_TRI) : uint32_t(OP_END);
+            uint32_t k = kind;
             int remaining;
             do {
                 if (k == OP_TRI) {
@@ -1090,7 +1105,8 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                 RTK_PROF_MARK(5, 1, remaining)
             } while (remaining >= keep);
         } else if (pick == W_SHADE) {
-            if (want == W_SHADE) {
+            if (kind == OP_END) {
+                bool alive = true;
                 const bool ended = L.depth <= 0 || shade<real, FEAT, COUNT>(L, prog, sc, mats, cam, cnt);
                 if (ended) {  // pixel_color += ray_color(...) (Camera.txt:72)
                     L.sum = L.sum + L.radiance;
@@ -1099,6 +1115,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                         begin_sample(L, cam, px_i, px_j, seed_hash, cnt);
                     } else {
                         alive = false;
+                        L.kind = OP_DEAD;
                         store_partial(partial, my_slot, my_pix, L.sum);
                         if (tile_cost && cost_tile >= 0) atomicAdd(&tile_cost[cost_tile], L.segs);  // no return value: fire and forget
                     }
@@ -1111,7 +1128,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             }
             RTK_PROF_MARK(3, 1, n_shd)
         } else {
-            if (want == W_OTHER) {
+            if (m_oth >> lane & 1ull) {
                 step_other<real, FEAT, COUNT>(L, prog + L.pc, sc, cnt);
                 L.kind = prog[L.pc].kind_payload & 15u;
             }

@@ -38,5 +38,5 @@ for v in variants:
         best = min(best, e0.elapsed_time(e1))
     d = hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest()[:12]
     digests.add(d)
-    print(f"{config} {'fast' if use_fast else 'reference'} variant {v:6d} (refill sel {(v >> 14) & 7}, box sel {(v >> 8) & 7}, sphere sel {(v >> 11) & 7}): {best:8.3f} ms  {n / best / 1e3:8.1f} Msamples/s  sha {d}", flush=True)
+    print(f"{config} {'fast' if use_fast else 'reference'} variant {v:6d} (fused-sphere sel {(v >> 17) & 7}, refill sel {(v >> 14) & 7}, box sel {(v >> 8) & 7}, sphere sel {(v >> 11) & 7}): {best:8.3f} ms  {n / best / 1e3:8.1f} Msamples/s  sha {d}", flush=True)
 print("all variants identical:", len(digests) == 1)

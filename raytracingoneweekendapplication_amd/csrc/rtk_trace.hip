@@ -185,7 +185,7 @@ RTK_DEV void unapply_chain(const ChainRec<real>* __restrict__ chains, uint32_t c
 // from 0*inf makes the comparison false, i.e. the reference's else-branch), and
 // max/min then drop a NaN operand exactly as its `>`/`<` updates do.
 // EXACT_NAN = false is for rays whose 1/d is finite and non-zero on every axis
-// (Lane::regular): then t0 and t1 cannot be NaN (bounds and origin are finite), and
+// (Lane::box_kind == OP_BOX): then t0 and t1 cannot be NaN (bounds and origin are finite), and
 // near = min(t0,t1), far = max(t0,t1) are the same values as the select -- five
 // instructions fewer per axis.  Rays with a zero or infinite direction component
 // take the exact form (the aabb known-answer vectors exercise them).
@@ -322,8 +322,11 @@ struct Lane {
     uint32_t pc, kind, best_pc, sv_best_pc, rng;  // kind = record kind at pc (kept in a register so the vote needs no LDS read)
     int depth, s;
     uint32_t segs;           // segments traced for the current (pixel, chunk): the tile-cost estimate
-    bool regular;            // 1/d finite and non-zero on all three axes: slab tests cannot produce NaNs
+    uint32_t box_kind;       // OP_BOX when 1/d is finite and non-zero on all three axes (slab tests cannot produce NaNs: the lane
+                             // joins the box loop); kIrregularBox otherwise (its boxes go through step_other's literal slab test)
 };
+
+constexpr uint32_t kIrregularBox = 0xFFu;  // matches no record kind
 
 template <typename real>
 RTK_DEV bool regular_direction(V3<real> inv) {
@@ -348,7 +351,7 @@ RTK_DEV void begin_segment(Lane<real>& L, Counters<COUNT>& cnt) {
     }
     L.inv = mk(real(1) / L.rd.x, real(1) / L.rd.y, real(1) / L.rd.z);
     L.a = length_squared(L.rd);
-    L.regular = regular_direction(L.inv);
+    L.box_kind = regular_direction(L.inv) ? uint32_t(OP_BOX) : kIrregularBox;
     L.oi = L.ro * L.inv;
     L.tmin = real(0.001);
     L.best_t = real_inf<real>();
@@ -385,7 +388,9 @@ RTK_DEV void step_other(Lane<real>& L, const Slot<real>* __restrict__ rec, const
     constexpr bool XF = (FEAT & F_XFORM) != 0;
     const uint32_t kp = rec->kind_payload;
     const uint32_t kind = kp & 15u;
-    if (kind == OP_SPHERE_MOVING) {
+    if (kind == OP_BOX) {  // only for rays with a zero or infinite direction component: the literal, NaN-exact slab test
+        step_box<true, XF>(L, *rec, cnt);
+    } else if (kind == OP_SPHERE_MOVING) {
         cnt.inc(C_SPHERE);
         real r;
         V3<real> cc = mk(rec->v[0], rec->v[1], rec->v[2]) + scale(L.tm, mk(rec[1].v[0], rec[1].v[1], rec[1].v[2]));
@@ -416,7 +421,7 @@ RTK_DEV void step_other(Lane<real>& L, const Slot<real>* __restrict__ rec, const
         apply_chain(sc.chains, kp >> 4, L.ro, L.rd, L.o, L.d);
         L.inv = mk(real(1) / L.d.x, real(1) / L.d.y, real(1) / L.d.z);
         L.a = length_squared(L.d);
-        L.regular = regular_direction(L.inv);
+        L.box_kind = regular_direction(L.inv) ? uint32_t(OP_BOX) : kIrregularBox;
         L.oi = L.o * L.inv;
         L.pc += 1;
     } else if ((FEAT & F_MEDIA) && kind == OP_MED_BEGIN) {
@@ -908,6 +913,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
     Lane<real> L;
     L.pc = end_pc;
     L.kind = OP_DEAD;                 // this lane owns no (pixel, chunk): it takes part in no vote and waits for a refill
+    L.box_kind = OP_BOX;              // (never left undefined: the vote compares kind with it on every lane)
     L.sum = mk(real(0), real(0), real(0));
     L.s = 0;
     RTK_PROF_DECL
@@ -974,7 +980,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
 
         // ---- vote (registers and scalar unit only).  A lane's record kind IS its vote; OP_DEAD lanes have none.
         const uint32_t kind = L.kind;
-        const unsigned long long m_box = __ballot(kind == OP_BOX);
+        const unsigned long long m_box = __ballot(kind == L.box_kind);  // irregular rays' boxes count as "other"
         const unsigned long long m_sph = __ballot(kind == OP_SPHERE);
         const unsigned long long m_shd = __ballot(kind == OP_END);
         const unsigned long long m_quad = (FEAT & F_QUAD) ? __ballot(kind == OP_QUAD) : 0ull;
@@ -1009,42 +1015,31 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             const int keep = frac > 8 ? frac : 8;
             Slot<real> cur = prog[L.pc];  // the record at L.pc, held in registers: one LDS round trip per step
             uint32_t k = kind;
+            const uint32_t box_kind = L.box_kind;  // a lane with an irregular ray matches nothing here: it never steps in this loop
             int remaining;
-            if (__ballot(kind == OP_BOX && !L.regular) == 0ull) {
-                // Sphere tests ride along: whenever `sphere_min` lanes of the wave sit on a sphere record, they are
-                // stepped here, inside the box loop, instead of waiting for the loop to drain and a vote to pick
-                // them (a vote round costs about three box steps).  Those lanes then return to box records, which
-                // also keeps the loop populated for longer.
-                do {
-                    if (k == OP_BOX) {
-                        step_box<false, (FEAT & F_XFORM) != 0, (FEAT & F_FMA_BOX) != 0>(L, cur, cnt);
+            // Sphere tests ride along: whenever `sphere_min` lanes of the wave sit on a sphere record, they are
+            // stepped here, inside the box loop, instead of waiting for the loop to drain and a vote to pick
+            // them (a vote round costs about two box steps).  Those lanes then return to box records, which
+            // also keeps the loop populated for longer.
+            do {
+                if (k == box_kind) {
+                    step_box<false, (FEAT & F_XFORM) != 0, (FEAT & F_FMA_BOX) != 0>(L, cur, cnt);
+                    cur = prog[L.pc];
+                    k = cur.kind_payload & 15u;
+                    L.kind = k;
+                }
+                if (popcount64(__ballot(k == OP_SPHERE)) >= sphere_min) {
+                    if (k == OP_SPHERE) {
+                        step_sphere<(FEAT & F_XFORM) != 0>(L, cur, cnt);
                         cur = prog[L.pc];
                         k = cur.kind_payload & 15u;
                         L.kind = k;
                     }
-                    if (popcount64(__ballot(k == OP_SPHERE)) >= sphere_min) {
-                        if (k == OP_SPHERE) {
-                            step_sphere<(FEAT & F_XFORM) != 0>(L, cur, cnt);
-                            cur = prog[L.pc];
-                            k = cur.kind_payload & 15u;
-                            L.kind = k;
-                        }
-                        RTK_PROF_MARK(2, 1, 0)
-                    }
-                    remaining = popcount64(__ballot(k == OP_BOX));
-                    RTK_PROF_MARK(1, 1, remaining)
-                } while (remaining >= keep);
-            } else {  // some lane has a ray with a zero/infinite direction component: literal NaN handling for this round
-                do {
-                    if (k == OP_BOX) {
-                        step_box<true, (FEAT & F_XFORM) != 0>(L, cur, cnt);
-                        cur = prog[L.pc];
-                        k = cur.kind_payload & 15u;
-                        L.kind = k;
-                    }
-                    remaining = popcount64(__ballot(k == OP_BOX));
-                } while (remaining >= keep);
-            }
+                    RTK_PROF_MARK(2, 1, 0)
+                }
+                remaining = popcount64(__ballot(k == box_kind));
+                RTK_PROF_MARK(1, 1, remaining)
+            } while (remaining >= keep);
         } else if (pick == W_SPHERE) {
             // A bvh leaf usually holds two spheres in a row: same amortisation, half the starters.
             const int ssel = int(diag >> 11) & 7;  // tools/: same for the sphere loop (0 = default)
@@ -1173,7 +1168,7 @@ __global__ __launch_bounds__(256) void rtk_debug_hit_kernel(SceneView<real> sc, 
         const uint32_t kind = rec->kind_payload & 15u;
         if (kind == OP_END) break;
         if (kind == OP_BOX) {
-            if (L.regular) step_box<false, true>(L, *rec, cnt);
+            if (L.box_kind == OP_BOX) step_box<false, true>(L, *rec, cnt);
             else step_box<true, true>(L, *rec, cnt);
         } else if (kind == OP_SPHERE) {
             step_sphere<true>(L, *rec, cnt);

@@ -301,6 +301,7 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
                 const rtk_sphere& s = sc.spheres[payload];
                 const double vals[4] = {s.center0.x, s.center0.y, s.center0.z, s.radius};
                 pack(rec, vals, 4);
+                rec->v[4] = real(1) / real(s.radius);  // the factor of `(p - center) / radius` (vec3.h:91-93), once instead of per hit
                 with_material(s.material);
                 if (kind == OP_SPHERE_MOVING) {
                     const double dir[3] = {s.center_dir.x, s.center_dir.y, s.center_dir.z};

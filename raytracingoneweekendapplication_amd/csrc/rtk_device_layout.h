@@ -35,7 +35,7 @@ enum OpKind : uint32_t {
     OP_END = 0,
     OP_BOX = 1,        // 1 slot : v = xmin,xmax,ymin,ymax,zmin,zmax; aux = pc to continue at when the slab test fails
     // primitive records: aux = chain id (bits 0..7) | material index (bits 8..31)
-    OP_SPHERE = 2,     // 1 slot : v = cx,cy,cz,radius (static sphere); payload = sphere index
+    OP_SPHERE = 2,     // 1 slot : v = cx,cy,cz,radius,1/radius (static sphere); payload = sphere index
     OP_QUAD = 3,       // 3 slots: n(3),D,Q(3),w(3),v(3),u(3) packed over the slots' v[]; payload = quad index
     OP_TRI = 4,        // 2 slots: e2(3),e1(3),p0(3); payload = triangle index
     OP_CHAIN = 5,      // 1 slot : payload = chain id to make current, aux = number of transform entries it stands for

@@ -241,18 +241,31 @@ RTK_DEV V3<real> packed3(const Slot<real>* rec) {
     return V3<real>{packed<real, E>(rec), packed<real, E + 1>(rec), packed<real, E + 2>(rec)};
 }
 
-// sphere::hit up to the accepted root (sphere.h:32-49); cc = center.at(r.time()).
+// n / a, correctly rounded, from y = RN(1/a) (computed once per segment by a true division): q0 = RN(n*y) is within
+// one ulp of the quotient, r = n - a*q0 is exact in one fused multiply-add, and q0 + r*y rounds to RN(n/a)
+// (Markstein's division step, the same correction the hardware division expansion ends with) -- three instructions
+// instead of the ~25 of a full f64 division.  tests/test_division_identity.py checks the identity against `/` on
+// 4e8 random operand pairs including all-ones significands.  (If q0 underflows the result is a denormal on either
+// path and fails the `tmin < root` test below either way.)
 template <typename real>
-RTK_DEV bool sphere_root(V3<real> cc, real radius, V3<real> o, V3<real> d, real a, real tmin, real tmax, real& root) {
+RTK_DEV real divide_by(real n, real a, real inv_a) {
+    const real q0 = n * inv_a;
+    const real r = rt_fma(-a, q0, n);
+    return rt_fma(r, inv_a, q0);
+}
+
+// sphere::hit up to the accepted root (sphere.h:32-49); cc = center.at(r.time()); a = d.d, inv_a = 1/a.
+template <typename real>
+RTK_DEV bool sphere_root(V3<real> cc, real radius, V3<real> o, V3<real> d, real a, real inv_a, real tmin, real tmax, real& root) {
     V3<real> oc = cc - o;
     real h = dot(d, oc);
     real c = length_squared(oc) - radius * radius;
     real disc = h * h - a * c;
     if (disc < real(0)) return false;
     real sq = rt_sqrt(disc);
-    real r = (h - sq) / a;
+    real r = divide_by(h - sq, a, inv_a);
     if (!(tmin < r && r < tmax)) {
-        r = (h + sq) / a;
+        r = divide_by(h + sq, a, inv_a);
         if (!(tmin < r && r < tmax)) return false;
     }
     root = r;
@@ -314,7 +327,7 @@ struct Lane {
     V3<real> ro, rd;         // world-space ray of the current segment (ray_color's `r`)
     V3<real> o, d, inv;      // the ray in the current chain's object space, and 1/d (aabb.h:67, hoisted: same value per box)
     V3<real> oi;             // o * inv, for the fused slab test of F_FMA_BOX kernels (dead, hence free, in the others)
-    real a, tm;              // d.d (sphere.h:35, hoisted likewise); ray time
+    real a, inv_a, tm;       // d.d (sphere.h:35, hoisted likewise) and 1/(d.d) for divide_by; ray time
     real tmin, best_t;       // current query interval: (tmin, closest so far)
     real sv_tmin, sv_best_t, rec1_t;  // constant_medium::hit nests two closest-hit queries of its boundary
                                       // (constant_medium.h:23,26); the outer query is parked here meanwhile
@@ -351,6 +364,7 @@ RTK_DEV void begin_segment(Lane<real>& L, Counters<COUNT>& cnt) {
     }
     L.inv = mk(real(1) / L.rd.x, real(1) / L.rd.y, real(1) / L.rd.z);
     L.a = length_squared(L.rd);
+    L.inv_a = real(1) / L.a;
     L.box_kind = regular_direction(L.inv) ? uint32_t(OP_BOX) : kIrregularBox;
     L.oi = L.ro * L.inv;
     L.tmin = real(0.001);
@@ -374,7 +388,7 @@ template <bool XF, typename real, bool COUNT>
 RTK_DEV void step_sphere(Lane<real>& L, const Slot<real>& rec, Counters<COUNT>& cnt) {
     cnt.inc(C_SPHERE);
     real r;
-    if (sphere_root(mk(rec.v[0], rec.v[1], rec.v[2]), rec.v[3], ray_o<XF>(L), ray_d<XF>(L), L.a, L.tmin, L.best_t, r)) {
+    if (sphere_root(mk(rec.v[0], rec.v[1], rec.v[2]), rec.v[3], ray_o<XF>(L), ray_d<XF>(L), L.a, L.inv_a, L.tmin, L.best_t, r)) {
         L.best_t = r;
         L.best_pc = L.pc;
     }
@@ -394,7 +408,7 @@ RTK_DEV void step_other(Lane<real>& L, const Slot<real>* __restrict__ rec, const
         cnt.inc(C_SPHERE);
         real r;
         V3<real> cc = mk(rec->v[0], rec->v[1], rec->v[2]) + scale(L.tm, mk(rec[1].v[0], rec[1].v[1], rec[1].v[2]));
-        if (sphere_root(cc, rec->v[3], ray_o<XF>(L), ray_d<XF>(L), L.a, L.tmin, L.best_t, r)) {
+        if (sphere_root(cc, rec->v[3], ray_o<XF>(L), ray_d<XF>(L), L.a, L.inv_a, L.tmin, L.best_t, r)) {
             L.best_t = r;
             L.best_pc = L.pc;
         }
@@ -421,6 +435,7 @@ RTK_DEV void step_other(Lane<real>& L, const Slot<real>* __restrict__ rec, const
         apply_chain(sc.chains, kp >> 4, L.ro, L.rd, L.o, L.d);
         L.inv = mk(real(1) / L.d.x, real(1) / L.d.y, real(1) / L.d.z);
         L.a = length_squared(L.d);
+        L.inv_a = real(1) / L.a;
         L.box_kind = regular_direction(L.inv) ? uint32_t(OP_BOX) : kIrregularBox;
         L.oi = L.o * L.inv;
         L.pc += 1;
@@ -585,7 +600,7 @@ RTK_DEV void make_surface(const Slot<real>* __restrict__ prog, const SceneView<r
     if (kind == OP_SPHERE || kind == OP_SPHERE_MOVING) {  // sphere.h:50-56,67-73
         V3<real> cc = mk(rec->v[0], rec->v[1], rec->v[2]);
         if (kind == OP_SPHERE_MOVING) cc = cc + scale(tm, mk(rec[1].v[0], rec[1].v[1], rec[1].v[2]));
-        outward = divide(sf.p - cc, rec->v[3]);
+        outward = scale(rec->v[4], sf.p - cc);  // (p - center) / radius = (1/radius) * (p - center) (vec3.h:91-93); v[4] = 1/radius from the upload
         if ((FEAT & F_TEXTURE) && (force_uv || mats[sf.material].needs_uv)) {
             const real pi = real(3.1415926535897932385);
             real theta = rt_acos(-outward.y);
@@ -907,7 +922,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
     // tools/: A/B of the refill batch size through variant bits 14..16 (0 = default)
     constexpr int kRefillMinTable[8] = {8, 1, 4, 8, 16, 24, 32, 12};
     const int refill_min = kRefillMinTable[(diag >> 14) & 7];
-    constexpr int kSphereMinTable[8] = {12, 65, 4, 8, 12, 16, 24, 32};  // variant bits 17..19; 65 = never (spheres only through the vote)
+    constexpr int kSphereMinTable[8] = {16, 65, 4, 8, 12, 16, 24, 32};  // variant bits 17..19; 65 = never (spheres only through the vote)
     const int sphere_min = kSphereMinTable[(diag >> 17) & 7];
 
     Lane<real> L;

@@ -452,6 +452,8 @@ void apply_overrides(rtk_view& v, int W, int H, int spp, int depth) {
 //   ref_driver time   <scene> <scene_seed> <image_file> W H spp depth seed threads
 //        prints one JSON line with Msamples/s
 //   ref_driver kat    <out_dir>
+//   ref_driver texels <image_file> <out_prefix>
+//        writes <out_prefix>.dims (two int32: width, height) and .u8: rtw_image's bytes (rtw_stb_image.h:53-121)
 int main(int argc, char** argv) {
     if (argc < 2) {
         std::fprintf(stderr, "usage: ref_driver desc|render|time|kat ...\n");
@@ -461,6 +463,18 @@ int main(int argc, char** argv) {
     if (cmd == "kat") {
         if (argc < 3) return 1;
         return write_kats(argv[2]);
+    }
+    if (cmd == "texels") {  // the bytes the reference's rtw_image (stbi_loadf + float_to_byte) holds for an image file
+        if (argc < 4) return 1;
+        rtw_image im;
+        if (!im.load(argv[2])) return 2;
+        const int w = im.width(), h = im.height();
+        std::vector<unsigned char> out(size_t(w) * h * 3);
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) std::memcpy(&out[(size_t(y) * w + x) * 3], im.pixel_data(x, y), 3);
+        const int dims[2] = {w, h};
+        std::string prefix = argv[3];
+        return (write_file(prefix + ".dims", dims, sizeof dims) && write_file(prefix + ".u8", out.data(), out.size())) ? 0 : 1;
     }
     if (argc < 5) return 1;
     std::string scene = argv[2];

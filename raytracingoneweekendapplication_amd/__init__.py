@@ -143,6 +143,8 @@ def host_lib() -> C.CDLL:
         lib.rtkh_scene_rng_draws.restype = C.c_uint64
         lib.rtkh_scene_rng_draws.argtypes = [C.c_void_p]
         lib.rtkh_scene_camera.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Camera)]
+        lib.rtkh_image_texels.restype = C.c_int64
+        lib.rtkh_image_texels.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_int64]
         _host_lib = lib
     return _host_lib
 
@@ -270,6 +272,20 @@ class FastOrderScene:
             self.close()
         except Exception:
             pass
+
+
+def load_image_texels(path: str):
+    """The RGB8 texels image_texture reads for an image file (PPM or baseline JPEG), as rtw_image holds them
+    (stbi_loadf's gamma-2.2 mapping and float_to_byte applied).  Returns an (H, W, 3) uint8 array or None."""
+    import numpy as np
+
+    w, h = C.c_int(), C.c_int()
+    n = host_lib().rtkh_image_texels(path.encode(), C.byref(w), C.byref(h), None, 0)
+    if n < 0:
+        return None
+    out = np.zeros((h.value, w.value, 3), np.uint8)
+    host_lib().rtkh_image_texels(path.encode(), C.byref(w), C.byref(h), out.ctypes.data, n)
+    return out
 
 
 def write_synthetic_earth(path: str, width: int = 1024, height: int = 512) -> str:

@@ -124,9 +124,9 @@ struct Optimizer {
     double prim_cost(int32_t kind) const { return opts.prim_cost_scale * base_prim_cost(kind); }
     static double base_prim_cost(int32_t kind) {  // measured ratios of the kernel's step costs, roughly
         switch (kind) {
-            case RTK_NODE_SPHERE: return 1.5;
-            case RTK_NODE_QUAD: return 2.5;
-            case RTK_NODE_TRIANGLE: return 2.5;
+            case RTK_NODE_SPHERE: return 2.1;   // A/B on the MI355X (tools/fast_order_probe.py, scale sweeps on C2 / C3 / C4):
+            case RTK_NODE_QUAD: return 1.75;    // a sphere step (square root + two quotients) weighs about two slab tests,
+            case RTK_NODE_TRIANGLE: return 1.75;  // quad and triangle steps somewhat less
             default: return 4.0;
         }
     }

@@ -1,0 +1,548 @@
+// rtk_jpeg.h -- baseline JPEG decoding for image_texture.
+//
+// The reference loads textures through rtw_image (rtw_stb_image.h:23-66), i.e.
+// stbi_loadf of the vendored stb_image.h: earthmap.jpg (main.cpp:152,311;
+// 1024x512, 4:4:4) and male_texture.jpg (main.cpp:383; 2048x2048, 4:2:0) are
+// baseline, 8-bit, three-component JFIF files.  The texels are INPUTS of the
+// sample loop, so for the drop-in to render what the reference renders the decoded
+// bytes must be the bytes stb_image produces, not merely a faithful JPEG decode:
+// JPEG leaves the inverse DCT, the chroma interpolation and the colour conversion
+// to the implementation, and they differ between libraries in the last bit.
+// This file therefore fixes those three choices to the ones stb_image makes
+// (written from the JPEG standard, ITU T.81, and the published algorithms named
+// below -- no code is taken from stb_image):
+//
+//   inverse DCT     Loeffler-Ligtenberg-Moschytz 8-point factorisation in 32-bit
+//                   integers with 12-bit constants; column pass keeps 2 extra bits
+//                   (+512 >> 10), row pass rounds at 17 bits with the +128 level
+//                   shift folded in, then clamps to 0..255.
+//   chroma upsample 4:2:0 / 4:2:2: "triangle" filter, 3/4 near + 1/4 far in each
+//                   direction, 16ths with +8 rounding (edges: (3 near + far + 2) >> 2);
+//                   4:4:4: none.  Other sampling ratios: pixel replication.
+//   YCbCr -> RGB    BT.601 full range in 20-bit fixed point: R = Y + 1.402 Cr,
+//                   G = Y - 0.71414 Cr - 0.34414 Cb (the Cb term truncated to its
+//                   upper 16 bits), B = Y + 1.772 Cb, with +0.5 before the shift.
+//
+// tests/test_image_decode.py pins the result byte for byte against the
+// reference's own loader (oracle/_ref) on generated fixtures and, where
+// /root/reference exists, on earthmap.jpg and male_texture.jpg themselves.
+//
+// Supported: SOF0 (baseline sequential) and SOF1 with 8-bit precision, 1 or 3
+// components, any sampling factors up to 4, restart intervals, 16-bit DQT
+// entries.  Not supported (load fails, width() == 0 as rtw_stb_image.h:62 has it on
+// a failed load): progressive (SOF2), arithmetic coding, 12-bit samples, CMYK.
+#ifndef RTK_JPEG_H
+#define RTK_JPEG_H
+
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace rtk {
+
+class jpeg_decoder {
+public:
+    // Decodes `data` to interleaved RGB8 (grey images are replicated to three channels, as stbi_load with
+    // req_comp = 3 does).  Returns false on malformed or unsupported input.
+    bool decode(const uint8_t* data, size_t size, int& width, int& height, std::vector<uint8_t>& rgb) {
+        src = data;
+        end = data + size;
+        if (size < 4 || src[0] != 0xFF || src[1] != 0xD8) return false;
+        src += 2;
+        restart_interval = 0;
+        n_comp = 0;
+        bool have_frame = false;
+        for (;;) {
+            int m = next_marker();
+            if (m < 0) return false;
+            if (m == 0xD9) return false;  // EOI before any scan
+            if (m == 0xDA) {
+                if (!have_frame || !read_scan_header()) return false;
+                if (!decode_scan()) return false;
+                break;  // baseline, interleaved: one scan carries the image (non-interleaved files loop below)
+            }
+            if (m == 0xC0 || m == 0xC1) {
+                if (have_frame || !read_frame_header()) return false;
+                have_frame = true;
+            } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
+                return false;  // progressive / lossless / arithmetic
+            } else if (m == 0xC4) {
+                if (!read_huffman_tables()) return false;
+            } else if (m == 0xDB) {
+                if (!read_quant_tables()) return false;
+            } else if (m == 0xDD) {
+                if (segment_length() != 4) return false;
+                restart_interval = (src[2] << 8) | src[3];
+                src += 4;
+            } else {
+                if (!skip_segment()) return false;
+            }
+        }
+        // Non-interleaved baseline files carry one scan per component: keep reading scans until EOI.
+        for (;;) {
+            int m = next_marker();
+            if (m < 0 || m == 0xD9) break;
+            if (m == 0xDA) {
+                if (!read_scan_header() || !decode_scan()) return false;
+            } else if (m == 0xC4) {
+                if (!read_huffman_tables()) return false;
+            } else if (m == 0xDB) {
+                if (!read_quant_tables()) return false;
+            } else if (m == 0xDD) {
+                if (segment_length() != 4) return false;
+                restart_interval = (src[2] << 8) | src[3];
+                src += 4;
+            } else if (!skip_segment()) {
+                break;
+            }
+        }
+        width = img_w;
+        height = img_h;
+        to_rgb(rgb);
+        return true;
+    }
+
+private:
+    struct huffman {
+        // canonical code: for each length L (1..16) the first code value, the index of its first symbol and the count
+        int32_t first_code[17], first_index[17], count[17];
+        uint8_t symbols[256];
+        bool present = false;
+    };
+    struct component {
+        int id, h, v, tq, td, ta;
+        int blocks_w, blocks_h;  // in 8x8 blocks, padded to whole MCUs
+        int plane_w, plane_h;
+        int dc_pred;
+        std::vector<uint8_t> plane;
+    };
+
+    const uint8_t* src = nullptr;
+    const uint8_t* end = nullptr;
+    int img_w = 0, img_h = 0, n_comp = 0, h_max = 1, v_max = 1, restart_interval = 0;
+    component comp[4];
+    uint16_t quant[4][64];
+    huffman dc_tab[4], ac_tab[4];
+    int scan_n = 0, scan_comp[4];
+    // bit reader
+    uint32_t bit_buf = 0;
+    int bit_cnt = 0;
+    bool hit_marker = false;
+
+    static const uint8_t* zigzag() {
+        static const uint8_t z[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                      41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                      30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+        return z;
+    }
+
+    int segment_length() const { return (end - src >= 2) ? ((src[0] << 8) | src[1]) : -1; }
+    bool skip_segment() {
+        int len = segment_length();
+        if (len < 2 || end - src < len) return false;
+        src += len;
+        return true;
+    }
+    int next_marker() {
+        while (src < end && *src != 0xFF) src++;  // tolerate stray bytes between segments
+        while (src < end && *src == 0xFF) src++;  // fill bytes
+        if (src >= end) return -1;
+        return *src++;
+    }
+
+    bool read_quant_tables() {
+        int len = segment_length();
+        if (len < 2 || end - src < len) return false;
+        const uint8_t* p = src + 2;
+        const uint8_t* stop = src + len;
+        while (p < stop) {
+            int precision = *p >> 4, id = *p & 15;
+            p++;
+            if (id > 3 || precision > 1) return false;
+            if (stop - p < (precision ? 128 : 64)) return false;
+            for (int k = 0; k < 64; k++) {
+                int v = precision ? ((p[0] << 8) | p[1]) : p[0];
+                p += precision ? 2 : 1;
+                quant[id][zigzag()[k]] = uint16_t(v);
+            }
+        }
+        src = stop;
+        return true;
+    }
+
+    bool read_huffman_tables() {
+        int len = segment_length();
+        if (len < 2 || end - src < len) return false;
+        const uint8_t* p = src + 2;
+        const uint8_t* stop = src + len;
+        while (p < stop) {
+            if (stop - p < 17) return false;
+            int cls = *p >> 4, id = *p & 15;
+            p++;
+            if (cls > 1 || id > 3) return false;
+            huffman& t = cls ? ac_tab[id] : dc_tab[id];
+            int total = 0, code = 0;
+            for (int L = 1; L <= 16; L++) {
+                t.count[L] = p[L - 1];
+                t.first_index[L] = total;
+                t.first_code[L] = code;
+                total += t.count[L];
+                code = (code + t.count[L]) << 1;
+            }
+            p += 16;
+            if (total > 256 || stop - p < total) return false;
+            std::memcpy(t.symbols, p, size_t(total));
+            p += total;
+            t.present = true;
+        }
+        src = stop;
+        return true;
+    }
+
+    bool read_frame_header() {
+        int len = segment_length();
+        if (len < 8 || end - src < len) return false;
+        const uint8_t* p = src + 2;
+        if (p[0] != 8) return false;  // sample precision
+        img_h = (p[1] << 8) | p[2];
+        img_w = (p[3] << 8) | p[4];
+        n_comp = p[5];
+        if (img_w <= 0 || img_h <= 0 || (n_comp != 1 && n_comp != 3) || len < 8 + 3 * n_comp) return false;
+        h_max = v_max = 1;
+        for (int c = 0; c < n_comp; c++) {
+            comp[c].id = p[6 + 3 * c];
+            comp[c].h = p[7 + 3 * c] >> 4;
+            comp[c].v = p[7 + 3 * c] & 15;
+            comp[c].tq = p[8 + 3 * c];
+            if (comp[c].h < 1 || comp[c].h > 4 || comp[c].v < 1 || comp[c].v > 4 || comp[c].tq > 3) return false;
+            if (comp[c].h > h_max) h_max = comp[c].h;
+            if (comp[c].v > v_max) v_max = comp[c].v;
+        }
+        const int mcu_w = 8 * h_max, mcu_h = 8 * v_max;
+        const int mcus_x = (img_w + mcu_w - 1) / mcu_w, mcus_y = (img_h + mcu_h - 1) / mcu_h;
+        for (int c = 0; c < n_comp; c++) {
+            comp[c].blocks_w = mcus_x * comp[c].h;
+            comp[c].blocks_h = mcus_y * comp[c].v;
+            comp[c].plane_w = comp[c].blocks_w * 8;
+            comp[c].plane_h = comp[c].blocks_h * 8;
+            comp[c].plane.assign(size_t(comp[c].plane_w) * comp[c].plane_h, 0);
+        }
+        src += len;
+        return true;
+    }
+
+    bool read_scan_header() {
+        int len = segment_length();
+        if (len < 6 || end - src < len) return false;
+        const uint8_t* p = src + 2;
+        scan_n = p[0];
+        if (scan_n < 1 || scan_n > n_comp || len != 6 + 2 * scan_n) return false;
+        for (int k = 0; k < scan_n; k++) {
+            int id = p[1 + 2 * k], which = -1;
+            for (int c = 0; c < n_comp; c++)
+                if (comp[c].id == id) which = c;
+            if (which < 0) return false;
+            comp[which].td = p[2 + 2 * k] >> 4;
+            comp[which].ta = p[2 + 2 * k] & 15;
+            if (comp[which].td > 3 || comp[which].ta > 3) return false;
+            scan_comp[k] = which;
+        }
+        const uint8_t* q = p + 1 + 2 * scan_n;
+        if (q[0] != 0 || q[1] != 63 || q[2] != 0) return false;  // spectral selection / approximation of a sequential scan
+        src += len;
+        return true;
+    }
+
+    // ---- entropy-coded segment
+    void reset_bits() {
+        bit_buf = 0;
+        bit_cnt = 0;
+        hit_marker = false;
+    }
+    void fill_bits() {
+        while (bit_cnt <= 24) {
+            uint32_t byte = 0;
+            if (!hit_marker && src < end) {
+                byte = *src;
+                if (byte == 0xFF) {
+                    uint32_t nxt = (src + 1 < end) ? src[1] : 0xD9;
+                    if (nxt == 0) {
+                        src += 2;  // stuffed zero
+                    } else {
+                        hit_marker = true;  // a marker: feed zeros from here on
+                        byte = 0;
+                    }
+                } else {
+                    src++;
+                }
+            }
+            bit_buf |= byte << (24 - bit_cnt);
+            bit_cnt += 8;
+        }
+    }
+    int get_bits(int n) {
+        if (n == 0) return 0;
+        if (bit_cnt < n) fill_bits();
+        int v = int(bit_buf >> (32 - n));
+        bit_buf <<= n;
+        bit_cnt -= n;
+        return v;
+    }
+    int decode_symbol(const huffman& t) {
+        if (bit_cnt < 16) fill_bits();
+        int code = 0;
+        for (int L = 1; L <= 16; L++) {
+            code = (code << 1) | int((bit_buf >> (32 - L)) & 1u);
+            if (t.count[L] && code - t.first_code[L] < t.count[L] && code >= t.first_code[L]) {
+                bit_buf <<= L;
+                bit_cnt -= L;
+                return t.symbols[t.first_index[L] + code - t.first_code[L]];
+            }
+        }
+        return -1;
+    }
+    static int extend(int v, int n) { return (n && v < (1 << (n - 1))) ? v - (1 << n) + 1 : v; }  // T.81 F.2.2.1
+
+    bool decode_block(component& c, int16_t coef[64]) {
+        const huffman& dc = dc_tab[c.td];
+        const huffman& ac = ac_tab[c.ta];
+        if (!dc.present || !ac.present) return false;
+        std::memset(coef, 0, 64 * sizeof(int16_t));
+        int s = decode_symbol(dc);
+        if (s < 0 || s > 15) return false;
+        int diff = s ? extend(get_bits(s), s) : 0;
+        c.dc_pred += diff;
+        const uint16_t* q = quant[c.tq];
+        coef[0] = int16_t(c.dc_pred * q[0]);
+        for (int k = 1; k < 64;) {
+            int rs = decode_symbol(ac);
+            if (rs < 0) return false;
+            int run = rs >> 4, size = rs & 15;
+            if (size == 0) {
+                if (run != 15) break;  // end of block
+                k += 16;
+                continue;
+            }
+            k += run;
+            if (k > 63) return false;
+            int pos = zigzag()[k];
+            coef[pos] = int16_t(extend(get_bits(size), size) * q[pos]);
+            k++;
+        }
+        return true;
+    }
+
+    // 8-point inverse DCT, Loeffler-Ligtenberg-Moschytz factorisation, 12-bit fixed-point constants.  `shifted`
+    // inputs: even part scaled by 4096; returns the eight butterfly outputs (before the final pairing) in e[] / o[].
+    static void idct_1d(const int32_t s[8], int32_t e[4], int32_t o[4]) {
+        constexpr int32_t c0_541 = 2217, c1_847 = -7567, c0_765 = 3135, c1_175 = 4816, c0_298 = 1223, c2_053 = 8410, c3_072 = 12586,
+                          c1_501 = 6149, c0_899 = -3685, c2_562 = -10497, c1_961 = -8034, c0_390 = -1597;
+        // even part
+        int32_t z = (s[2] + s[6]) * c0_541;
+        int32_t t2 = z + s[6] * c1_847, t3 = z + s[2] * c0_765;
+        int32_t t0 = (s[0] + s[4]) * 4096, t1 = (s[0] - s[4]) * 4096;
+        e[0] = t0 + t3;
+        e[3] = t0 - t3;
+        e[1] = t1 + t2;
+        e[2] = t1 - t2;
+        // odd part
+        int32_t a0 = s[7], a1 = s[5], a2 = s[3], a3 = s[1];
+        int32_t p3 = a0 + a2, p4 = a1 + a3, p1 = a0 + a3, p2 = a1 + a2;
+        int32_t p5 = (p3 + p4) * c1_175;
+        a0 *= c0_298;
+        a1 *= c2_053;
+        a2 *= c3_072;
+        a3 *= c1_501;
+        p1 = p5 + p1 * c0_899;
+        p2 = p5 + p2 * c2_562;
+        p3 *= c1_961;
+        p4 *= c0_390;
+        o[3] = a3 + p1 + p4;
+        o[2] = a2 + p2 + p3;
+        o[1] = a1 + p2 + p4;
+        o[0] = a0 + p1 + p3;
+    }
+    static uint8_t clamp8(int32_t v) { return uint8_t(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+    static void idct_block(const int16_t coef[64], uint8_t* out, int stride) {
+        int32_t tmp[64];
+        for (int x = 0; x < 8; x++) {  // columns: keep two fractional bits
+            int32_t s[8], e[4], o[4];
+            for (int k = 0; k < 8; k++) s[k] = coef[x + 8 * k];
+            idct_1d(s, e, o);
+            for (int k = 0; k < 4; k++) e[k] += 512;
+            tmp[x + 0] = (e[0] + o[3]) >> 10;
+            tmp[x + 56] = (e[0] - o[3]) >> 10;
+            tmp[x + 8] = (e[1] + o[2]) >> 10;
+            tmp[x + 48] = (e[1] - o[2]) >> 10;
+            tmp[x + 16] = (e[2] + o[1]) >> 10;
+            tmp[x + 40] = (e[2] - o[1]) >> 10;
+            tmp[x + 24] = (e[3] + o[0]) >> 10;
+            tmp[x + 32] = (e[3] - o[0]) >> 10;
+        }
+        for (int y = 0; y < 8; y++) {  // rows: round at 17 bits, +128 level shift folded in
+            int32_t e[4], o[4];
+            idct_1d(tmp + 8 * y, e, o);
+            for (int k = 0; k < 4; k++) e[k] += 65536 + (128 << 17);
+            uint8_t* row = out + y * stride;
+            row[0] = clamp8((e[0] + o[3]) >> 17);
+            row[7] = clamp8((e[0] - o[3]) >> 17);
+            row[1] = clamp8((e[1] + o[2]) >> 17);
+            row[6] = clamp8((e[1] - o[2]) >> 17);
+            row[2] = clamp8((e[2] + o[1]) >> 17);
+            row[5] = clamp8((e[2] - o[1]) >> 17);
+            row[3] = clamp8((e[3] + o[0]) >> 17);
+            row[4] = clamp8((e[3] - o[0]) >> 17);
+        }
+    }
+
+    bool decode_scan() {
+        reset_bits();
+        for (int c = 0; c < n_comp; c++) comp[c].dc_pred = 0;
+        int16_t coef[64];
+        int todo = restart_interval ? restart_interval : 0x7fffffff;
+        auto after_unit = [&]() -> bool {
+            if (--todo > 0) return true;
+            // a restart marker must follow: byte-align, check RSTn, reset predictors
+            reset_bits_to_marker();
+            if (src + 1 < end && src[0] == 0xFF && src[1] >= 0xD0 && src[1] <= 0xD7) {
+                src += 2;
+                reset_bits();
+                for (int c = 0; c < n_comp; c++) comp[c].dc_pred = 0;
+                todo = restart_interval ? restart_interval : 0x7fffffff;
+                return true;
+            }
+            return true;  // no marker (end of scan, or a damaged file): keep what was decoded
+        };
+        if (scan_n == 1) {  // non-interleaved: the component's own blocks in raster order, (w+7)/8 x (h+7)/8 of them
+            component& c = comp[scan_comp[0]];
+            const int w = (((img_w * c.h + h_max - 1) / h_max) + 7) >> 3, h = (((img_h * c.v + v_max - 1) / v_max) + 7) >> 3;
+            for (int by = 0; by < h; by++)
+                for (int bx = 0; bx < w; bx++) {
+                    if (!decode_block(c, coef)) return false;
+                    idct_block(coef, c.plane.data() + size_t(by) * 8 * c.plane_w + bx * 8, c.plane_w);
+                    if (!after_unit()) return false;
+                }
+        } else {
+            const int mcus_x = comp[0].blocks_w / comp[0].h, mcus_y = comp[0].blocks_h / comp[0].v;
+            for (int my = 0; my < mcus_y; my++)
+                for (int mx = 0; mx < mcus_x; mx++) {
+                    for (int k = 0; k < scan_n; k++) {
+                        component& c = comp[scan_comp[k]];
+                        for (int v = 0; v < c.v; v++)
+                            for (int h = 0; h < c.h; h++) {
+                                if (!decode_block(c, coef)) return false;
+                                const int bx = mx * c.h + h, by = my * c.v + v;
+                                idct_block(coef, c.plane.data() + size_t(by) * 8 * c.plane_w + bx * 8, c.plane_w);
+                            }
+                    }
+                    if (!after_unit()) return false;
+                }
+        }
+        reset_bits_to_marker();
+        return true;
+    }
+    // Leave `src` at the marker that ended the entropy-coded data (bytes already pulled into the bit buffer are
+    // never past it: fill_bits stops consuming at a marker).
+    void reset_bits_to_marker() {
+        if (!hit_marker) {
+            // whole bytes still sitting in the buffer belong to the stream; scan forward to the next marker
+            while (src + 1 < end && !(src[0] == 0xFF && src[1] != 0 && !(src[1] == 0xFF))) src++;
+        }
+        bit_buf = 0;
+        bit_cnt = 0;
+        hit_marker = false;
+    }
+
+    // ---- planes -> RGB
+    // One output row of a component at full resolution: the triangle-filtered (h2 and/or v2) or replicated samples.
+    void upsample_row(const component& c, int y, std::vector<uint8_t>& row, std::vector<uint8_t>& scratch) const {
+        const int hs = h_max / c.h, vs = v_max / c.v;
+        const int cw = (img_w * c.h + h_max - 1) / h_max;  // the component's own width in samples
+        const int ch = (img_h * c.v + v_max - 1) / v_max;
+        auto line = [&](int r) { return c.plane.data() + size_t(r < 0 ? 0 : (r >= ch ? ch - 1 : r)) * c.plane_w; };
+        row.resize(size_t(cw) * hs + 8);
+        if (hs == 1 && vs == 1) {
+            std::memcpy(row.data(), line(y), size_t(cw));
+        } else if (hs == 1 && vs == 2) {
+            // vertical only: (3 near + far + 2) >> 2
+            const int src_row = y >> 1;
+            const uint8_t* near_ = line(src_row);
+            const uint8_t* far_ = line((y & 1) ? src_row + 1 : src_row - 1);
+            for (int i = 0; i < cw; i++) row[i] = uint8_t((3 * near_[i] + far_[i] + 2) >> 2);
+        } else if (hs == 2 && vs == 1) {
+            const uint8_t* in = line(y);
+            h2_row(in, cw, row.data());
+        } else if (hs == 2 && vs == 2) {
+            const int src_row = y >> 1;
+            const uint8_t* near_ = line(src_row);
+            const uint8_t* far_ = line((y & 1) ? src_row + 1 : src_row - 1);
+            if (cw == 1) {
+                row[0] = row[1] = uint8_t((3 * near_[0] + far_[0] + 2) >> 2);
+            } else {
+                // vertical blend kept at 4x scale, horizontal blend on top: 16ths with +8 rounding
+                int t1 = 3 * near_[0] + far_[0];
+                row[0] = uint8_t((t1 + 2) >> 2);
+                for (int i = 1; i < cw; i++) {
+                    const int t0 = t1;
+                    t1 = 3 * near_[i] + far_[i];
+                    row[2 * i - 1] = uint8_t((3 * t0 + t1 + 8) >> 4);
+                    row[2 * i] = uint8_t((3 * t1 + t0 + 8) >> 4);
+                }
+                row[2 * cw - 1] = uint8_t((t1 + 2) >> 2);
+            }
+        } else {
+            // any other ratio: nearest sample
+            const uint8_t* in = line(y / vs);
+            for (int i = 0; i < cw; i++)
+                for (int k = 0; k < hs; k++) row[size_t(i) * hs + k] = in[i];
+        }
+        (void)scratch;
+    }
+    static void h2_row(const uint8_t* in, int w, uint8_t* out) {
+        if (w == 1) {
+            out[0] = out[1] = in[0];
+            return;
+        }
+        out[0] = in[0];
+        out[1] = uint8_t((in[0] * 3 + in[1] + 2) >> 2);
+        for (int i = 1; i < w - 1; i++) {
+            const int n = 3 * in[i] + 2;
+            out[2 * i] = uint8_t((n + in[i - 1]) >> 2);
+            out[2 * i + 1] = uint8_t((n + in[i + 1]) >> 2);
+        }
+        out[2 * (w - 1)] = uint8_t((in[w - 2] * 3 + in[w - 1] + 2) >> 2);
+        out[2 * (w - 1) + 1] = in[w - 1];
+    }
+
+    void to_rgb(std::vector<uint8_t>& rgb) const {
+        rgb.assign(size_t(img_w) * img_h * 3, 0);
+        std::vector<uint8_t> rows[3], scratch;
+        for (int y = 0; y < img_h; y++) {
+            for (int c = 0; c < n_comp; c++) upsample_row(comp[c], y, rows[c], scratch);
+            uint8_t* out = rgb.data() + size_t(y) * img_w * 3;
+            if (n_comp == 1) {
+                for (int x = 0; x < img_w; x++) out[3 * x] = out[3 * x + 1] = out[3 * x + 2] = rows[0][x];
+                continue;
+            }
+            for (int x = 0; x < img_w; x++) {
+                const int yf = (int(rows[0][x]) << 20) + (1 << 19);
+                const int cb = int(rows[1][x]) - 128, cr = int(rows[2][x]) - 128;
+                // 1.40200, 0.71414, 0.34414, 1.77200 as round(x * 4096) << 8
+                int r = yf + cr * (5743 << 8);
+                int g = yf + cr * -(2925 << 8) + int(uint32_t(cb * -(1410 << 8)) & 0xffff0000u);
+                int b = yf + cb * (7258 << 8);
+                r >>= 20;
+                g >>= 20;
+                b >>= 20;
+                out[3 * x] = clamp8(r);
+                out[3 * x + 1] = clamp8(g);
+                out[3 * x + 2] = clamp8(b);
+            }
+        }
+    }
+};
+
+}  // namespace rtk
+
+#endif  // RTK_JPEG_H

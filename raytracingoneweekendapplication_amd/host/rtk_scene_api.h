@@ -21,12 +21,14 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <string>
 #include <unordered_map>
 #include <vector>
 
 #include "glm_min.h"  // glm::vec2 for triangle UVs (triangle.h:137-139); the full GLM is not a dependency
 #include "rtk.h"
+#include "rtk_jpeg.h"
 #include "rtk_math.h"
 
 namespace rtk {
@@ -111,9 +113,10 @@ public:
 }  // namespace rtk
 
 // ===========================================================================
-// Image data behind image_texture (reference: rtw_stb_image.h).  Decoding JPEG
-// is host asset I/O outside the path; this loader reads
-// binary PPM (P6) and raw RGB8 buffers.  The reference pipeline is
+// Image data behind image_texture (reference: rtw_stb_image.h).  This loader
+// reads baseline JPEG (rtk_jpeg.h: the reference's earthmap.jpg / male_texture.jpg,
+// decoded to the very bytes stb_image yields -- SURVEY 8(f) row 4), binary PPM
+// (P6) and raw RGB8 buffers.  The reference pipeline is
 // stbi_loadf -> float -> float_to_byte (rtw_stb_image.h:53-66,99-121), i.e. the
 // texels the sample loop sees are int(256 * (b/255)^2.2); from_file applies the
 // same mapping so that a PPM gives the bytes the reference would hold.
@@ -144,28 +147,55 @@ public:
     bool load(const std::string& path) {
         std::ifstream f(path, std::ios::binary);
         if (!f.good()) return false;
-        std::string magic;
-        f >> magic;
-        if (magic != "P6") return false;
-        int vals[3], got = 0;
-        while (got < 3 && f.good()) {
-            int c = f.peek();
-            if (c == '#') { std::string skip; std::getline(f, skip); continue; }
-            if (isspace(c)) { f.get(); continue; }
-            f >> vals[got++];
+        std::vector<uint8_t> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        std::vector<uint8_t> raw;
+        int iw = 0, ih = 0;
+        if (file.size() > 3 && file[0] == 0xFF && file[1] == 0xD8) {
+            rtk::jpeg_decoder jpeg;  // baseline JPEG, decoded to the bytes stb_image produces (rtk_jpeg.h)
+            if (!jpeg.decode(file.data(), file.size(), iw, ih, raw)) return false;
+        } else if (!parse_ppm(file, iw, ih, raw)) {
+            return false;
         }
-        if (got < 3 || vals[2] != 255) return false;
-        f.get();
-        std::vector<uint8_t> raw(size_t(vals[0]) * vals[1] * 3);
-        f.read(reinterpret_cast<char*>(raw.data()), std::streamsize(raw.size()));
-        if (size_t(f.gcount()) != raw.size()) return false;
-        w = vals[0];
-        h = vals[1];
+        w = iw;
+        h = ih;
         bytes.resize(raw.size());
-        for (size_t i = 0; i < raw.size(); i++) {
-            float lin = float(std::pow(raw[i] / 255.0f, 2.2f) * 1.0f);  // stbi ldr->hdr
-            bytes[i] = lin <= 0.0 ? 0 : (1.0 <= lin ? 255 : static_cast<unsigned char>(256.0 * lin));
+        // stbi_loadf turns 8-bit data into "linear" floats, pow(b/255, 2.2) in float (stb_image.h:1858-1873), and
+        // rtw_image::float_to_byte (rtw_stb_image.h:99-105) truncates 256*v: that is what the sample loop sees
+        uint8_t map[256];
+        for (int b = 0; b < 256; b++) {
+            float lin = float(std::pow(b / 255.0f, 2.2f) * 1.0f);
+            map[b] = lin <= 0.0 ? 0 : (1.0 <= lin ? 255 : static_cast<unsigned char>(256.0 * lin));
         }
+        for (size_t i = 0; i < raw.size(); i++) bytes[i] = map[raw[i]];
+        return true;
+    }
+    // Binary PPM (P6, maxval 255).
+    static bool parse_ppm(const std::vector<uint8_t>& file, int& iw, int& ih, std::vector<uint8_t>& raw) {
+        if (file.size() < 2 || file[0] != 'P' || file[1] != '6') return false;
+        size_t pos = 2;
+        int vals[3], got = 0;
+        while (got < 3 && pos < file.size()) {
+            const int c = file[pos];
+            if (c == '#') {
+                while (pos < file.size() && file[pos] != '\n') pos++;
+                continue;
+            }
+            if (isspace(c)) {
+                pos++;
+                continue;
+            }
+            if (c < '0' || c > '9') return false;
+            int v = 0;
+            while (pos < file.size() && file[pos] >= '0' && file[pos] <= '9') v = v * 10 + (file[pos++] - '0');
+            vals[got++] = v;
+        }
+        if (got < 3 || vals[2] != 255 || vals[0] <= 0 || vals[1] <= 0) return false;
+        pos++;  // the single whitespace byte after maxval
+        const size_t n = size_t(vals[0]) * vals[1] * 3;
+        if (file.size() - pos < n) return false;
+        raw.assign(file.begin() + long(pos), file.begin() + long(pos + n));
+        iw = vals[0];
+        ih = vals[1];
         return true;
     }
     int width() const { return bytes.empty() ? 0 : w; }

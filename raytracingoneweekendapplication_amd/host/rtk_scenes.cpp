@@ -4,6 +4,7 @@
 // A small C interface lets bench.py / the tests obtain the flattened scene and
 // the derived camera without a C++ toolchain on the GPU box.  Nothing here traces
 // rays; rendering is rtk_render_* of librtk_hip.so.
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -90,6 +91,19 @@ int rtkh_scene_camera(const rtkh_scene* s, int width, int height, int spp, int d
         *out = cam.derive();
     }
     return out->image_height == v.image_height ? 0 : -2;
+}
+
+// The texels rtw_image holds for an image file (PPM or baseline JPEG), i.e. what image_texture::value reads
+// (texture.h:90-104).  Returns the byte count (width * height * 3) and fills `out` when it is large enough;
+// -1 when the file cannot be loaded (rtw_stb_image.h:62: width() == 0).
+int64_t rtkh_image_texels(const char* path, int* width, int* height, uint8_t* out, int64_t capacity) {
+    rtw_image im;
+    if (!path || !im.load(path)) return -1;
+    if (width) *width = im.width();
+    if (height) *height = im.height();
+    const int64_t n = int64_t(im.data().size());
+    if (out && capacity >= n) std::memcpy(out, im.data().data(), size_t(n));
+    return n;
 }
 
 }  // extern "C"

@@ -61,5 +61,43 @@ def main():
     json.dump(hashes, open(os.path.join(HERE, "desc_sha256.json"), "w"), indent=1, sort_keys=True)
 
 
+
+
+def make_jpeg_fixtures():
+    """Small baseline JPEGs written by Pillow (synthetic content) + the bytes the REFERENCE's rtw_image holds for
+    them (ref_driver texels): 4:4:4, 4:2:0, 4:2:2, grey, sizes that are not multiples of the MCU, restart markers."""
+    from PIL import Image
+
+    rng = np.random.default_rng(20250418)
+    cases = {
+        "jpg_444_40x24": dict(size=(40, 24), subsampling=0, quality=90),
+        "jpg_420_37x23": dict(size=(37, 23), subsampling=2, quality=85),
+        "jpg_420_1x1": dict(size=(1, 1), subsampling=2, quality=85),
+        "jpg_420_17x9_rst": dict(size=(17, 9), subsampling=2, quality=70, restart_marker_blocks=1),
+        "jpg_422_33x16": dict(size=(33, 16), subsampling=1, quality=95),
+        "jpg_grey_19x21": dict(size=(19, 21), grey=True, quality=80),
+        "jpg_420_64x64_noise": dict(size=(64, 64), subsampling=2, quality=60, noise=True),
+    }
+    for name, c in cases.items():
+        w, h = c["size"]
+        y, x = np.mgrid[0:h, 0:w]
+        if c.get("noise"):
+            img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        else:
+            img = np.stack([(x * 7 + y * 3) % 256, (255 - x * 5 + y * 11) % 256, (x * y + 40 * np.sin(x / 3.0)) % 256], -1).astype(np.uint8)
+        path = os.path.join(HERE, name + ".jpg")
+        kw = {k: v for k, v in c.items() if k in ("quality", "subsampling", "restart_marker_blocks")}
+        im = Image.fromarray(img[:, :, 0] if c.get("grey") else img, "L" if c.get("grey") else "RGB")
+        im.save(path, "JPEG", optimize=False, progressive=False, **kw)
+        prefix = os.path.join(tempfile.mkdtemp(), name)
+        subprocess.check_call([REF, "texels", path, prefix])
+        dims = np.fromfile(prefix + ".dims", np.int32)
+        assert dims.tolist() == [w, h], (name, dims)
+        np.save(os.path.join(HERE, name + "_texels.npy"), np.fromfile(prefix + ".u8", np.uint8).reshape(h, w, 3))
+        print(name, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if "--jpeg-only" not in sys.argv:
+        main()
+    make_jpeg_fixtures()

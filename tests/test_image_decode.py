@@ -1,0 +1,65 @@
+"""CPU tests of image-texture loading (rtw_stb_image.h:23-121).
+
+The texels are inputs of the sample loop, so the loader must hand the kernels the very bytes the reference's
+rtw_image holds: stb_image's JPEG decode (its integer inverse DCT, its chroma filter, its fixed-point colour
+conversion), then stbi_loadf's gamma-2.2 float mapping, then float_to_byte.  The golden arrays were dumped from
+the reference's own loader (oracle/_ref `texels`, tests/golden/make_goldens.py) for small JPEGs written by Pillow;
+where the reference tree exists its two real textures are compared live as well.
+"""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN
+
+FIXTURES = ["jpg_444_40x24", "jpg_420_37x23", "jpg_420_1x1", "jpg_420_17x9_rst", "jpg_422_33x16", "jpg_grey_19x21", "jpg_420_64x64_noise"]
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_jpeg_texels_equal_the_reference_loaders_bytes(rt, name):
+    got = rt.load_image_texels(os.path.join(GOLDEN, name + ".jpg"))
+    want = np.load(os.path.join(GOLDEN, name + "_texels.npy"), allow_pickle=False)
+    assert got is not None and got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+def test_ppm_goes_through_the_same_byte_mapping(rt):
+    got = rt.load_image_texels(os.path.join(GOLDEN, "earth_synth.ppm"))
+    raw = open(os.path.join(GOLDEN, "earth_synth.ppm"), "rb").read()
+    body = np.frombuffer(raw[raw.index(b"255\n") + 4:], np.uint8).reshape(32, 64, 3)
+    lin = np.power(body.astype(np.float32) / np.float32(255.0), np.float32(2.2)).astype(np.float32)
+    want = np.where(lin <= 0, 0, np.where(lin >= 1, 255, (256.0 * lin.astype(np.float64)).astype(np.int64))).astype(np.uint8)
+    assert got.shape == (32, 64, 3)
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1   # powf vs numpy's float32 power may differ in the last ulp
+    assert (got == want).mean() > 0.99
+
+
+def test_unsupported_and_damaged_files_fail_to_load(rt):
+    assert rt.load_image_texels(os.path.join(GOLDEN, "jpg_progressive_16x16.jpg")) is None   # SOF2: not decoded here
+    assert rt.load_image_texels("/nonexistent/file.jpg") is None
+    data = open(os.path.join(GOLDEN, "jpg_420_37x23.jpg"), "rb").read()
+    with tempfile.TemporaryDirectory() as tmp:
+        for cut in (3, 20, 200):
+            p = os.path.join(tmp, f"cut{cut}.jpg")
+            open(p, "wb").write(data[:cut])
+            assert rt.load_image_texels(p) is None
+        p = os.path.join(tmp, "garbage.jpg")
+        open(p, "wb").write(b"\xff\xd8" + bytes(range(256)) * 4)
+        assert rt.load_image_texels(p) is None
+
+
+def test_reference_textures_decode_identically_where_the_reference_exists(rt, orc):
+    files = ["/root/reference/Images/earthmap.jpg", "/root/reference/male_texture.jpg"]
+    if not (os.path.exists(orc.REF_DRIVER) and all(os.path.exists(f) for f in files)):
+        pytest.skip("needs /root/reference and oracle/_ref (build container only)")
+    for f in files:
+        with tempfile.TemporaryDirectory() as tmp:
+            prefix = os.path.join(tmp, "t")
+            subprocess.check_call([orc.REF_DRIVER, "texels", f, prefix])
+            w, h = np.fromfile(prefix + ".dims", np.int32).tolist()
+            want = np.fromfile(prefix + ".u8", np.uint8).reshape(h, w, 3)
+        got = rt.load_image_texels(f)
+        assert got is not None and np.array_equal(got, want), f

@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             // threshold wins: leaving the loop costs a vote plus an exposed LDS round trip,
             // which is worth more than the lanes that idle for a few extra steps.
             const int sel = int(diag >> 8) & 7;  // tools/: A/B of the loop-exit threshold, in eighths of the starters (0 = default)
-            const int eighths = sel == 0 ? 3 : sel;  // measured on C2: 3/8 of the starters is the sweet spot (2/8..4/8 within 1 %)
+            const int eighths = sel == 0 ? 2 : sel;  // measured on C2 (votes now cost ~2 box steps, spheres ride along): 2/8 of the starters 30.9 ms, 3/8 31.8, 4/8 32.4
             const int frac = (n_box * eighths) >> 3;
             const int keep = frac > 8 ? frac : 8;
             Slot<real> cur = prog[L.pc];  // the record at L.pc, held in registers: one LDS round trip per step

@@ -6,9 +6,11 @@
 // compute entry point fails with RTK_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -261,8 +263,80 @@ void store3(real* dst, const rtk_vec3& v) {
     dst[2] = real(v.z);
 }
 
+// Outward rounding of a box bound to float.
+inline float round_down(double x) {
+    float f = float(x);
+    return double(f) > x ? std::nextafterf(f, -INFINITY) : f;
+}
+inline float round_up(double x) {
+    float f = float(x);
+    return double(f) < x ? std::nextafterf(f, INFINITY) : f;
+}
+
+// The MIXED program of rtk_device_layout.h for a sphere-only scene whose boxes carry rtk_scene_optimize's margin:
+// f32 culling boxes (rounded outward, then grown by 2^-19 of the largest coordinate in play), f64 spheres.
+// Error budget of the f32 slab test t = fma(b, inv32, -(o32 * inv32)) with inv32 = rcp(float(d)) (1 ulp), o32 =
+// float(o): |b*inv| 2^-22.4 + |o*inv| 2^-22 + |t| 2^-24, i.e. a plane displaced by less than 2^-21 (|b| + |o|)
+// <= 2^-20 x extent -- half the margin.  The kernel sends rays whose origin leaves [-extent, extent]^3 through the
+// exact test instead (they cannot come from a surface of the scene).
+static void build_mixed_program(const rtk_scene_desc& sc, const Program& prog, double eye_extent, std::vector<MixedHead>& units, float& extent_out) {
+    auto kind_of = [&](const Op& op) -> uint32_t {
+        uint32_t kind = op.kind_payload & 15u;
+        if (kind == OP_SPHERE) {
+            const rtk_sphere& s = sc.spheres[op.kind_payload >> 4];
+            if (s.center_dir.x != 0 || s.center_dir.y != 0 || s.center_dir.z != 0) kind = OP_SPHERE_MOVING;
+        }
+        return kind;
+    };
+    std::vector<uint32_t> unit_of_op(prog.ops.size() + 1, 0);
+    double extent = eye_extent;
+    for (size_t i = 0; i < prog.ops.size(); i++) {
+        const Op& op = prog.ops[i];
+        unit_of_op[i + 1] = unit_of_op[i] + uint32_t(mixed_units(kind_of(op)));
+        if ((op.kind_payload & 15u) == OP_BOX) {
+            const rtk_aabb& b = sc.bvh_boxes[op.kind_payload >> 4];
+            for (double v : {b.xmin, b.xmax, b.ymin, b.ymax, b.zmin, b.zmax}) extent = std::max(extent, std::fabs(v));
+        } else if ((op.kind_payload & 15u) == OP_SPHERE) {
+            const rtk_sphere& s = sc.spheres[op.kind_payload >> 4];
+            for (double c : {s.center0.x, s.center0.y, s.center0.z, s.center0.x + s.center_dir.x, s.center0.y + s.center_dir.y, s.center0.z + s.center_dir.z})
+                extent = std::max(extent, std::fabs(c) + s.radius);
+        }
+    }
+    extent = double(round_up(extent * 1.0000001));
+    const double margin = std::ldexp(extent, -19);  // (A/B on C2: a margin 128 times smaller renders 0.7 % faster -- nothing to gain)
+    units.assign(unit_of_op.back(), MixedHead{});
+    std::memset(units.data(), 0, units.size() * sizeof(MixedHead));
+    for (size_t i = 0; i < prog.ops.size(); i++) {
+        const Op& op = prog.ops[i];
+        const uint32_t kind = kind_of(op), payload = op.kind_payload >> 4;
+        MixedHead* rec = &units[unit_of_op[i]];
+        rec->kind_payload = make_op(kind, payload);
+        rec->aux = op.aux;
+        if (kind == OP_BOX) {
+            const rtk_aabb& b = sc.bvh_boxes[payload];
+            rec->f[0] = round_down(b.xmin - margin); rec->f[1] = round_up(b.xmax + margin);
+            rec->f[2] = round_down(b.ymin - margin); rec->f[3] = round_up(b.ymax + margin);
+            rec->f[4] = round_down(b.zmin - margin); rec->f[5] = round_up(b.zmax + margin);
+            rec->aux = unit_of_op[op.aux];
+        } else if (kind == OP_SPHERE || kind == OP_SPHERE_MOVING) {
+            const rtk_sphere& s = sc.spheres[payload];
+            rec->d[0] = s.center0.x; rec->d[1] = s.center0.y; rec->d[2] = s.center0.z;
+            double* cont = reinterpret_cast<double*>(rec + 1);
+            cont[0] = s.radius;
+            cont[1] = 1.0 / s.radius;
+            if (kind == OP_SPHERE_MOVING) {
+                cont[2] = s.center_dir.x;
+                cont[3] = s.center_dir.y;
+                cont[4] = s.center_dir.z;  // first double of the third unit
+            }
+            rec->aux = (op.aux & 255u) | (uint32_t(s.material) << 8);
+        }
+    }
+    extent_out = float(extent);
+}
+
 template <typename real>
-int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScene<real>& out) {
+int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScene<real>& out, bool want_mixed = false, double eye_extent = 0.0) {
     out.release();
     // ---- the fused traversal program: one or more slots per op, skip links
     // translated from op indices to slot indices
@@ -440,6 +514,17 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
     out.view.n_slots = int32_t(slots.size());
     out.view.n_lights = sc.n_lights;
     out.view.n_materials = sc.n_materials;
+    out.view.program_mixed = nullptr;
+    out.view.n_units = 0;
+    out.view.extent = 0.0f;
+    if constexpr (sizeof(real) == 8) {
+        if (want_mixed) {
+            std::vector<MixedHead> units;
+            build_mixed_program(sc, prog, eye_extent, units, out.view.extent);
+            if ((rc = out.upload(units, &out.view.program_mixed)) != RTK_OK) return rc;
+            out.view.n_units = int32_t(units.size());
+        }
+    }
     return RTK_OK;
 }
 
@@ -544,7 +629,7 @@ int rtk_destroy(rtk_ctx* ctx) {
     return RTK_OK;
 }
 
-static int upload_scene(rtk_ctx* ctx, const rtk_scene_desc* scene, uint32_t hierarchy_flags);
+static int upload_scene(rtk_ctx* ctx, const rtk_scene_desc* scene, uint32_t hierarchy_flags, double eye_extent = 0.0);
 
 int rtk_scene_upload(rtk_ctx* ctx, const rtk_scene_desc* scene) {
     if (!ctx || !scene) return fail(RTK_ERR_INVALID, "rtk_scene_upload: null argument");
@@ -557,12 +642,14 @@ int rtk_scene_upload_fast(rtk_ctx* ctx, const rtk_scene_desc* scene, const rtk_o
     int rc = rtk_scene_optimize(scene, opts, &fast, info);
     if (rc != RTK_OK) return fail(rc, "rtk_scene_upload_fast: rtk_scene_optimize rejected the scene description");
     // every box of `fast` was grown by rtk_scene_optimize's margin: the kernels may use the fused slab test
-    rc = upload_scene(ctx, fast, F_FMA_BOX);
+    double eye_extent = 0.0;
+    if (opts && opts->has_eye) eye_extent = std::max(std::fabs(opts->eye.x), std::max(std::fabs(opts->eye.y), std::fabs(opts->eye.z)));
+    rc = upload_scene(ctx, fast, F_FMA_BOX, eye_extent);
     rtk_scene_optimized_free(fast);
     return rc;
 }
 
-static int upload_scene(rtk_ctx* ctx, const rtk_scene_desc* scene, uint32_t hierarchy_flags) {
+static int upload_scene(rtk_ctx* ctx, const rtk_scene_desc* scene, uint32_t hierarchy_flags, double eye_extent) {
     int rc = validate_tables(*scene);
     if (rc != RTK_OK) return rc;
     Program prog;
@@ -583,7 +670,9 @@ static int upload_scene(rtk_ctx* ctx, const rtk_scene_desc* scene, uint32_t hier
     RTK_HIP(hipSetDevice(ctx->device));
     ctx->has_scene = false;
     ctx->order_valid = false;  // a new scene: tile costs measured on the old one mean nothing
-    if ((rc = build_device_scene<double>(*scene, prog, ctx->scene64)) != RTK_OK) return rc;
+    // sphere-only scenes in the fast order additionally get the MIXED program (f32 culling boxes) for the f64 kernels
+    const bool want_mixed = (hierarchy_flags & F_FMA_BOX) != 0 && prog.features == kFeatLean && prog.chains.size() <= 1;
+    if ((rc = build_device_scene<double>(*scene, prog, ctx->scene64, want_mixed, eye_extent)) != RTK_OK) return rc;
     if ((rc = build_device_scene<float>(*scene, prog, ctx->scene32)) != RTK_OK) return rc;
     ctx->features = prog.features | hierarchy_flags;
     ctx->n_ops = int32_t(prog.ops.size());
@@ -669,7 +758,7 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
     unsigned int* tile_counter = ctx->tile_counters + slot;
     unsigned char* d_cam = ctx->d_cameras + slot * kCameraStride;
     const bool allow_lds = (opts->variant & 1) == 0;  // variant bit 0: keep the program in global memory (A/B)
-    const uint32_t diag = uint32_t(opts->variant) & 0xFFF00u;  // bits 8..19: scheduler policy A/B used by tools/ only
+    const uint32_t diag = uint32_t(opts->variant) & 0x1FFF00u;  // bits 8..20: scheduler policy / program layout A/B used by tools/ only
     hipError_t e;
     if (opts->real_mode == RTK_REAL_F64) {
         ctx->h_cameras64[slot] = to_device_camera<double>(*cam);
@@ -799,8 +888,9 @@ int rtk_scene_info(rtk_ctx* ctx, int32_t* n_program_ops, int64_t* bytes_f64, int
 const char* rtk_kernel_name(rtk_ctx* ctx, int real_mode, int variant) {
     if (!ctx || !ctx->has_scene) return "";
     const bool f64 = real_mode == RTK_REAL_F64;
-    const bool lds = (variant & 1) == 0 && (f64 ? program_fits_lds(ctx->scene64.view) : program_fits_lds(ctx->scene32.view));
-    return render_kernel_name(f64, ctx->features, false, lds);
+    const bool mixed = f64 && ctx->scene64.view.program_mixed != nullptr && (variant & (1 << 20)) == 0;
+    const bool lds = (variant & 1) == 0 && (f64 ? program_fits_lds(ctx->scene64.view, mixed) : program_fits_lds(ctx->scene32.view, false));
+    return render_kernel_name(f64, ctx->features, false, lds, mixed);
 }
 
 }  // extern "C"

@@ -66,6 +66,24 @@ inline constexpr int slots_of(uint32_t kind) {
     return kind == OP_QUAD ? 3 : ((kind == OP_TRI || kind == OP_SPHERE_MOVING) ? 2 : 1);
 }
 
+// The MIXED traversal program (F_F32_BOX): records are sequences of 32-byte units, pc counts units.  The first unit of
+// every record carries the header at bytes 24..31, so the kind of the record at pc is always one 8-byte read away:
+//   OP_BOX            1 unit : f[0..5] = xmin,xmax,ymin,ymax,zmin,zmax as floats, rounded OUTWARD and grown (see
+//                              rtk_api.cpp); aux = pc to continue at when the slab test fails
+//   OP_SPHERE         2 units: d[0..2] = centre (f64); unit 1 = radius, 1/radius (f64)
+//   OP_SPHERE_MOVING  3 units: as OP_SPHERE; unit 1 also holds dx, dy; unit 2 holds dz (centre2 - centre1)
+//   OP_END            1 unit
+// A culling box only decides which primitives get tested; the tests themselves, and so the hit, stay exact f64.
+struct alignas(16) MixedHead {
+    union {
+        float f[6];
+        double d[3];
+    };
+    uint32_t kind_payload, aux;
+};
+static_assert(sizeof(MixedHead) == 32, "mixed unit size");
+inline constexpr int mixed_units(uint32_t kind) { return kind == OP_SPHERE ? 2 : (kind == OP_SPHERE_MOVING ? 3 : 1); }
+
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 constexpr int kMaxChain = 4;
 constexpr int kMaxChunks = 64;
@@ -82,7 +100,10 @@ enum Feature : uint32_t {
     F_EXOTIC_MAT = 1u << 6,  // isotropic / specular / diffuse_light
     // Not a scene feature but a property of the uploaded hierarchy: its boxes carry rtk_scene_optimize's margin, so the
     // slab test may use the fused form (rtk_scene_upload_fast).  Orthogonal to the bits above.
-    F_FMA_BOX = 1u << 7
+    F_FMA_BOX = 1u << 7,
+    // f64 kernels only, sphere-only scenes: the MIXED program below -- conservative f32 culling boxes in 32-byte
+    // records, exact f64 primitive tests (rtk_scene_upload_fast picks it when the scene qualifies).
+    F_F32_BOX = 1u << 8
 };
 constexpr uint32_t kFeatLean = 0;                       // spheres + lambertian/metal/dielectric with solid colours
 constexpr uint32_t kFeatAll = 0x7F;
@@ -152,6 +173,11 @@ struct SceneView {  // device pointers, passed to the kernel by value
     const ChainRec<real>* chains;
     const LightRec<real>* lights;
     int32_t n_slots, n_lights, n_materials;
+    // MIXED program (F_F32_BOX kernels; null otherwise) and the coordinate bound its box margin was sized for: a ray
+    // whose origin lies outside [-extent, extent]^3 takes the exact f64 slab test instead of the f32 one
+    const MixedHead* program_mixed;
+    int32_t n_units;
+    float extent;
 };
 
 struct TileMap {  // which tiles this launch renders and where the pixels go

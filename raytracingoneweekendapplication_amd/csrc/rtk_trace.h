@@ -29,7 +29,7 @@ hipError_t launch_resolve(const void* partial, const TileMap& tmap, int width, i
 
 // Whether the traversal program of `sc` can be staged in one CU's LDS.
 template <typename real>
-bool program_fits_lds(const SceneView<real>& sc);
+bool program_fits_lds(const SceneView<real>& sc, bool mixed = false);
 
 // Known-answer helper: closest hit of the scene root for n caller-supplied rays (device buffers).
 template <typename real>
@@ -40,7 +40,7 @@ template <typename real>
 hipError_t launch_unpermute(const void* gathered, int width, int height, int n_ranks, long long tiles_per_rank, void* out_linear, uint8_t* out_rgb8,
                             hipStream_t stream);
 
-const char* render_kernel_name(bool f64, uint32_t features, bool count, bool lds);
+const char* render_kernel_name(bool f64, uint32_t features, bool count, bool lds, bool mixed);
 
 }  // namespace rtk
 

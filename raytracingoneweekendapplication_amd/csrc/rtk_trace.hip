@@ -24,6 +24,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "rtk.h"
 #include "rtk_device_layout.h"
@@ -85,6 +86,8 @@ RTK_DEV double raw_min(double a, double b) { double r; asm("v_min_f64 %0, %1, %2
 RTK_DEV double raw_max(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 RTK_DEV float raw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 RTK_DEV float raw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RTK_DEV float raw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+RTK_DEV float raw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 template <typename real> RTK_DEV V3<real> unit_vector(V3<real> a) { return divide(a, rt_sqrt(length_squared(a))); }
 template <typename real> RTK_DEV bool near_zero(V3<real> a) {
     const real s = real(1e-8);
@@ -327,6 +330,10 @@ struct Lane {
     V3<real> ro, rd;         // world-space ray of the current segment (ray_color's `r`)
     V3<real> o, d, inv;      // the ray in the current chain's object space, and 1/d (aabb.h:67, hoisted: same value per box)
     V3<real> oi;             // o * inv, for the fused slab test of F_FMA_BOX kernels (dead, hence free, in the others)
+    // F_F32_BOX kernels: the ray as the f32 culling boxes see it -- 1/d and o/d in float, the query interval rounded
+    // outward.  inv and oi above are dead there.
+    V3<float> inv32, oi32;
+    float tmin32, tmax32;
     real a, inv_a, tm;       // d.d (sphere.h:35, hoisted likewise) and 1/(d.d) for divide_by; ray time
     real tmin, best_t;       // current query interval: (tmin, closest so far)
     real sv_tmin, sv_best_t, rec1_t;  // constant_medium::hit nests two closest-hit queries of its boundary
@@ -353,26 +360,126 @@ RTK_DEV bool regular_direction(V3<real> inv) {
 template <bool XF, typename real> RTK_DEV const V3<real>& ray_o(const Lane<real>& L) { if constexpr (XF) return L.o; else return L.ro; }
 template <bool XF, typename real> RTK_DEV const V3<real>& ray_d(const Lane<real>& L) { if constexpr (XF) return L.d; else return L.rd; }
 
+// The f64 query interval (tmin, best_t) as the f32 slab test uses it: rounded outward, so nothing the exact interval
+// admits is rejected.  A float conversion rounds to nearest (error <= 2^-24 relative); scaling by 1 -/+ 2^-22 moves
+// the bound safely past the exact value; infinities stay infinities.
+RTK_DEV float below(double x) { const float f = float(x); return f - __builtin_fabsf(f) * 2.3841858e-07f; }
+RTK_DEV float above(double x) { const float f = float(x); return f + __builtin_fabsf(f) * 2.3841858e-07f; }
+RTK_DEV float below(float x) { return x; }
+RTK_DEV float above(float x) { return x; }
+
+template <typename real>
+RTK_DEV void sync_interval32(Lane<real>& L) {
+    L.tmin32 = below(L.tmin);
+    L.tmax32 = above(L.best_t);
+}
+
+// F_F32_BOX: 1/d and o/d in float for the culling boxes (one v_rcp_f32 per axis instead of an f64 division), and
+// whether the f32 test may be used at all: direction components neither zero nor beyond float range, origin inside
+// the coordinate bound the box margin was sized for (rtk_api.cpp build_mixed_program).
+template <typename real>
+RTK_DEV void begin_culling32(Lane<real>& L, V3<real> o, V3<real> d, float extent) {
+    const V3<float> d32 = V3<float>{float(d.x), float(d.y), float(d.z)};
+    L.inv32 = V3<float>{__builtin_amdgcn_rcpf(d32.x), __builtin_amdgcn_rcpf(d32.y), __builtin_amdgcn_rcpf(d32.z)};
+    L.oi32 = V3<float>{float(o.x) * L.inv32.x, float(o.y) * L.inv32.y, float(o.z) * L.inv32.z};
+    const float big = 3.0e38f;
+    const bool ok = __builtin_fabsf(L.inv32.x) < big && __builtin_fabsf(L.inv32.y) < big && __builtin_fabsf(L.inv32.z) < big &&
+                    __builtin_fabsf(d32.x) < big && __builtin_fabsf(d32.y) < big && __builtin_fabsf(d32.z) < big &&
+                    __builtin_fabsf(d32.x) > 1.0e-30f && __builtin_fabsf(d32.y) > 1.0e-30f && __builtin_fabsf(d32.z) > 1.0e-30f &&
+                    __builtin_fabsf(float(o.x)) <= extent && __builtin_fabsf(float(o.y)) <= extent && __builtin_fabsf(float(o.z)) <= extent;
+    L.box_kind = ok ? uint32_t(OP_BOX) : kIrregularBox;
+}
+
 // world.hit(r, interval(0.001, inf), rec) (Camera.txt:211) starts here.
-template <bool XF, typename real, bool COUNT>
-RTK_DEV void begin_segment(Lane<real>& L, Counters<COUNT>& cnt) {
+template <bool XF, bool MIXED = false, typename real, bool COUNT>
+RTK_DEV void begin_segment(Lane<real>& L, Counters<COUNT>& cnt, float extent = 0.0f) {
     cnt.inc(C_SEGMENTS);
     L.segs += 1;
     if constexpr (XF) {
         L.o = L.ro;
         L.d = L.rd;
     }
-    L.inv = mk(real(1) / L.rd.x, real(1) / L.rd.y, real(1) / L.rd.z);
     L.a = length_squared(L.rd);
     L.inv_a = real(1) / L.a;
-    L.box_kind = regular_direction(L.inv) ? uint32_t(OP_BOX) : kIrregularBox;
-    L.oi = L.ro * L.inv;
     L.tmin = real(0.001);
     L.best_t = real_inf<real>();
+    if constexpr (MIXED) {
+        begin_culling32(L, L.ro, L.rd, extent);
+        sync_interval32(L);
+    } else {
+        L.inv = mk(real(1) / L.rd.x, real(1) / L.rd.y, real(1) / L.rd.z);
+        L.box_kind = regular_direction(L.inv) ? uint32_t(OP_BOX) : kIrregularBox;
+        L.oi = L.ro * L.inv;
+    }
     L.best_pc = kNoHit;
     L.pc = 0;
 }
 
+// ---- F_F32_BOX: the steps on the MIXED program (rtk_device_layout.h) -----------------------------------------
+// Conservative slab test in float: the same min/max structure as slab_test_fma on bounds that were rounded outward
+// and grown for exactly this arithmetic.  v_max3/v_min3 fold the reduction.
+RTK_DEV bool slab_test32(const MixedHead& b, V3<float> oi, V3<float> inv, float tmin, float tmax) {
+    const float t0x = __builtin_fmaf(b.f[0], inv.x, -oi.x), t1x = __builtin_fmaf(b.f[1], inv.x, -oi.x);
+    const float t0y = __builtin_fmaf(b.f[2], inv.y, -oi.y), t1y = __builtin_fmaf(b.f[3], inv.y, -oi.y);
+    const float t0z = __builtin_fmaf(b.f[4], inv.z, -oi.z), t1z = __builtin_fmaf(b.f[5], inv.z, -oi.z);
+    const float nx = raw_min(t0x, t1x), fx = raw_max(t0x, t1x);
+    const float ny = raw_min(t0y, t1y), fy = raw_max(t0y, t1y);
+    const float nz = raw_min(t0z, t1z), fz = raw_max(t0z, t1z);
+    const float near = raw_max(raw_max3(nx, ny, nz), tmin);
+    const float far = raw_min(raw_min3(fx, fy, fz), tmax);
+    return far >= near;  // >= : a tie is let through (conservative)
+}
+template <typename real, bool COUNT>
+RTK_DEV void step_box32(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cnt) {
+    cnt.inc(C_BOX);
+    const bool hit = slab_test32(rec, L.oi32, L.inv32, L.tmin32, L.tmax32);
+    L.pc = hit ? L.pc + 1 : rec.aux;
+}
+// A box of the MIXED program for a ray the float test must not judge (zero / out-of-range direction component, origin
+// outside the sized bound): aabb::hit's literal form in f64 on the (outward-rounded, hence still enclosing) bounds.
+template <typename real, bool COUNT>
+RTK_DEV void step_box_mixed_exact(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cnt) {
+    cnt.inc(C_BOX);
+    Slot<real> b;
+    for (int k = 0; k < 6; k++) b.v[k] = real(rec.f[k]);
+    const V3<real> inv = mk(real(1) / L.rd.x, real(1) / L.rd.y, real(1) / L.rd.z);
+    const bool hit = slab_test<true>(b, L.ro, inv, L.tmin, L.best_t);
+    L.pc = hit ? L.pc + 1 : rec.aux;
+}
+// sphere::hit on a MIXED record: centre in the head unit, radius in the next one.
+template <typename real, bool COUNT>
+RTK_DEV void step_sphere_mixed(Lane<real>& L, const MixedHead& head, const MixedHead* __restrict__ rec, Counters<COUNT>& cnt) {
+    cnt.inc(C_SPHERE);
+    const double radius = reinterpret_cast<const double*>(rec + 1)[0];
+    real r;
+    if (sphere_root(mk(real(head.d[0]), real(head.d[1]), real(head.d[2])), real(radius), L.ro, L.rd, L.a, L.inv_a, L.tmin, L.best_t, r)) {
+        L.best_t = r;
+        L.best_pc = L.pc;
+        L.tmax32 = above(r);
+    }
+    L.pc += 2;
+}
+// The remaining record kinds of a sphere-only program: a moving sphere, or a box for an irregular ray.
+template <typename real, bool COUNT>
+RTK_DEV void step_other_mixed(Lane<real>& L, const MixedHead* __restrict__ rec, Counters<COUNT>& cnt) {
+    const uint32_t kind = rec->kind_payload & 15u;
+    if (kind == OP_BOX) {
+        step_box_mixed_exact(L, *rec, cnt);
+    } else if (kind == OP_SPHERE_MOVING) {
+        cnt.inc(C_SPHERE);
+        const double* cont = reinterpret_cast<const double*>(rec + 1);
+        const V3<real> cc = mk(real(rec->d[0]), real(rec->d[1]), real(rec->d[2])) + scale(L.tm, mk(real(cont[2]), real(cont[3]), real(cont[4])));
+        real r;
+        if (sphere_root(cc, real(cont[0]), L.ro, L.rd, L.a, L.inv_a, L.tmin, L.best_t, r)) {
+            L.best_t = r;
+            L.best_pc = L.pc;
+            L.tmax32 = above(r);
+        }
+        L.pc += 3;
+    } else {
+        L.pc += uint32_t(mixed_units(kind));  // unreachable for a validated sphere-only program
+    }
+}
 // bvh_node::hit's box test (bvh.h:65): on a miss skip the whole subtree.
 template <bool EXACT_NAN, bool XF, bool FMA = false, typename real, bool COUNT>
 RTK_DEV void step_box(Lane<real>& L, const Slot<real>& rec, Counters<COUNT>& cnt) {
@@ -579,6 +686,24 @@ struct Surface {  // hit_record (hittable.h:11-27)
     bool front_face;
 };
 
+// The deferred hit record of a MIXED program's winner (sphere.h:50-56; solid colours only: no uv).
+template <typename real>
+RTK_DEV void make_surface_mixed(const MixedHead* __restrict__ prog, uint32_t best_pc, real t, V3<real> wo, V3<real> wd, real tm, Surface<real>& sf) {
+    const MixedHead* rec = prog + best_pc;
+    const uint32_t kind = rec->kind_payload & 15u;
+    const double* cont = reinterpret_cast<const double*>(rec + 1);
+    sf.material = int(rec->aux >> 8);
+    sf.p = wo + scale(t, wd);
+    sf.u = real(0);
+    sf.v = real(0);
+    V3<real> cc = mk(real(rec->d[0]), real(rec->d[1]), real(rec->d[2]));
+    if (kind == OP_SPHERE_MOVING) cc = cc + scale(tm, mk(real(cont[2]), real(cont[3]), real(cont[4])));
+    const V3<real> outward = scale(real(cont[1]), sf.p - cc);
+    sf.front_face = dot(wd, outward) < real(0);
+    sf.normal = sf.front_face ? outward : -outward;
+}
+
+
 // Build the hit record of the winning record (the deferred half of *.hit).  Sphere
 // and quad geometry is read from the program slot itself (LDS when staged); only
 // triangles go to their side record for the normal and the UVs.
@@ -688,8 +813,8 @@ RTK_DEV void begin_sample(Lane<real>& L, const CameraRec<real>& cam, int i, int 
 // The traversal program ran to OP_END: the body of ray_color after world.hit
 // (Camera.txt:211-237), iteratively (radiance = sum of throughput * emission).
 // Returns true when the sample's path has ended.
-template <typename real, uint32_t FEAT, bool COUNT>
-RTK_DEV bool shade(Lane<real>& L, const Slot<real>* __restrict__ prog, const SceneView<real>& sc, const MaterialRec<real>* __restrict__ mats,
+template <typename real, uint32_t FEAT, bool COUNT, typename ProgT>
+RTK_DEV bool shade(Lane<real>& L, const ProgT* __restrict__ prog, const SceneView<real>& sc, const MaterialRec<real>* __restrict__ mats,
                    const CameraRec<real>& cam, Counters<COUNT>& cnt) {
     if (L.best_pc == kNoHit) {  // Camera.txt:211-213
         L.radiance = L.radiance + L.throughput * ld3(cam.background);
@@ -697,7 +822,8 @@ RTK_DEV bool shade(Lane<real>& L, const Slot<real>* __restrict__ prog, const Sce
     }
     cnt.inc(C_SURFACE);
     Surface<real> sf;
-    make_surface<real, FEAT>(prog, sc, mats, L.best_pc, L.best_t, L.ro, L.rd, L.tm, sf);
+    if constexpr (FEAT & F_F32_BOX) make_surface_mixed(prog, L.best_pc, L.best_t, L.ro, L.rd, L.tm, sf);
+    else make_surface<real, FEAT>(prog, sc, mats, L.best_pc, L.best_t, L.ro, L.rd, L.tm, sf);
     const MaterialRec<real>& m = mats[sf.material];
     const V3<real> rd = L.rd;
 
@@ -873,7 +999,7 @@ RTK_DEV void store_partial(real* __restrict__ partial, int item, int pix, V3<rea
 // the full-feature kernel, which needs far more registers (~560 B/lane of spills at 168), is fastest at 2 waves.
 template <typename real, uint32_t FEAT>
 constexpr int max_threads() {
-    constexpr uint32_t scene_feat = FEAT & ~uint32_t(F_FMA_BOX);
+    constexpr uint32_t scene_feat = FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX);
     if (sizeof(real) == 8) return scene_feat == kFeatAll ? 512 : ((scene_feat == kFeatLean || scene_feat == kFeatQuadBox) ? 1024 : 768);
     return 768;
 }
@@ -884,18 +1010,24 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                                                           unsigned int* __restrict__ tile_counter, const int32_t* __restrict__ tile_order,
                                                           unsigned int* __restrict__ tile_cost, uint32_t diag) {
     extern __shared__ __align__(16) unsigned char lds_program[];
-    const Slot<real>* prog = sc.program;
+    constexpr bool MIXED = (FEAT & F_F32_BOX) != 0;  // the MIXED program: f32 culling boxes, 32-byte units (f64, sphere-only scenes)
+    static_assert(!MIXED || (sizeof(real) == 8 && (FEAT & ~uint32_t(F_F32_BOX)) == kFeatLean && !COUNT), "F_F32_BOX: lean f64 kernels only");
+    using ProgRec = std::conditional_t<MIXED, MixedHead, Slot<real>>;
+    const ProgRec* prog;
+    if constexpr (MIXED) prog = sc.program_mixed;
+    else prog = sc.program;
+    const int n_records = MIXED ? sc.n_units : sc.n_slots;  // units of sizeof(ProgRec)
     const MaterialRec<real>* mats = sc.materials;
     if constexpr (IN_LDS) {  // program, then the material table, both as 16-byte words
-        const int n_prog16 = sc.n_slots * int(sizeof(Slot<real>) / 16);
+        const int n_prog16 = n_records * int(sizeof(ProgRec) / 16);
         const int n_mat16 = sc.n_materials * int(sizeof(MaterialRec<real>) / 16);
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(sc.program);
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(prog);
         const uint4* __restrict__ msrc = reinterpret_cast<const uint4*>(sc.materials);
         uint4* dst = reinterpret_cast<uint4*>(lds_program);
         for (int k = threadIdx.x; k < n_prog16; k += blockDim.x) dst[k] = src[k];
         for (int k = threadIdx.x; k < n_mat16; k += blockDim.x) dst[n_prog16 + k] = msrc[k];
         __syncthreads();
-        prog = reinterpret_cast<const Slot<real>*>(lds_program);
+        prog = reinterpret_cast<const ProgRec*>(lds_program);
         mats = reinterpret_cast<const MaterialRec<real>*>(lds_program + size_t(n_prog16) * 16);
     }
     // The camera lives in device memory and is read with scalar loads where it is
@@ -906,7 +1038,8 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
     const uint32_t seed_hash = pcg_hash(seed);
     const int n_tiles_total = tmap.tiles_x * tmap.tiles_y;
     const int width = cam.width, height = cam.height, spp = cam.spp;
-    const uint32_t end_pc = uint32_t(sc.n_slots - 1);
+    const uint32_t end_pc = uint32_t(n_records - 1);  // OP_END is one unit in either layout
+    const float extent = sc.extent;
     Counters<COUNT> cnt;
     cnt.clear();
 
@@ -969,7 +1102,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                 L.segs = 0;
                 cost_tile = chunk == 0 ? local_tile : -1;  // chunk 0 of every pixel reports the tile's cost
                 begin_sample(L, cam, px_i, px_j, seed_hash, cnt);
-                if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0>(L, cnt);
+                if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0, MIXED>(L, cnt, extent);
                 else L.pc = end_pc;  // max_depth == 0: ray_color returns black at once (Camera.txt:205-206)
                 L.kind = prog[L.pc].kind_payload & 15u;
             }
@@ -1028,7 +1161,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             const int eighths = sel == 0 ? 2 : sel;  // measured on C2 (votes now cost ~2 box steps, spheres ride along): 2/8 of the starters 30.9 ms, 3/8 31.8, 4/8 32.4
             const int frac = (n_box * eighths) >> 3;
             const int keep = frac > 8 ? frac : 8;
-            Slot<real> cur = prog[L.pc];  // the record at L.pc, held in registers: one LDS round trip per step
+            ProgRec cur = prog[L.pc];  // the record at L.pc (its first 32 bytes in the MIXED layout), held in registers: one LDS round trip per step
             uint32_t k = kind;
             const uint32_t box_kind = L.box_kind;  // a lane with an irregular ray matches nothing here: it never steps in this loop
             int remaining;
@@ -1038,14 +1171,16 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             // also keeps the loop populated for longer.
             do {
                 if (k == box_kind) {
-                    step_box<false, (FEAT & F_XFORM) != 0, (FEAT & F_FMA_BOX) != 0>(L, cur, cnt);
+                    if constexpr (MIXED) step_box32(L, cur, cnt);
+                    else step_box<false, (FEAT & F_XFORM) != 0, (FEAT & F_FMA_BOX) != 0>(L, cur, cnt);
                     cur = prog[L.pc];
                     k = cur.kind_payload & 15u;
                     L.kind = k;
                 }
                 if (popcount64(__ballot(k == OP_SPHERE)) >= sphere_min) {
                     if (k == OP_SPHERE) {
-                        step_sphere<(FEAT & F_XFORM) != 0>(L, cur, cnt);
+                        if constexpr (MIXED) step_sphere_mixed(L, cur, prog + L.pc, cnt);
+                        else step_sphere<(FEAT & F_XFORM) != 0>(L, cur, cnt);
                         cur = prog[L.pc];
                         k = cur.kind_payload & 15u;
                         L.kind = k;
@@ -1060,12 +1195,13 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             const int ssel = int(diag >> 11) & 7;  // tools/: same for the sphere loop (0 = default)
             const int sfrac = (n_sph * (ssel == 0 ? 4 : ssel)) >> 3;
             const int keep = sfrac > 8 ? sfrac : 8;
-            Slot<real> cur = prog[L.pc];
+            ProgRec cur = prog[L.pc];
             uint32_t k = kind;
             int remaining;
             do {
                 if (k == OP_SPHERE) {
-                    step_sphere<(FEAT & F_XFORM) != 0>(L, cur, cnt);
+                    if constexpr (MIXED) step_sphere_mixed(L, cur, prog + L.pc, cnt);
+                    else step_sphere<(FEAT & F_XFORM) != 0>(L, cur, cnt);
                     cur = prog[L.pc];
                     k = cur.kind_payload & 15u;
                     L.kind = k;
@@ -1074,6 +1210,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                 RTK_PROF_MARK(2, 1, remaining)
             } while (remaining >= keep);
         } else if ((FEAT & F_QUAD) && pick == W_QUAD) {
+          if constexpr ((FEAT & F_QUAD) != 0) {
             // quad::hit.  A box() is six quads in a row (quad.h:86-108): stay while at least half the starters do.
             const int keep = (n_quad >> 1) > 8 ? (n_quad >> 1) : 8;
             uint32_t k = kind;
@@ -1093,7 +1230,9 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                 remaining = popcount64(__ballot(k == OP_QUAD));
                 RTK_PROF_MARK(5, 1, remaining)
             } while (remaining >= keep);
+          }
         } else if ((FEAT & F_TRI) && pick == W_TRI) {
+          if constexpr ((FEAT & F_TRI) != 0) {
             // triangle::hit; a bvh leaf holds one or two triangles.
             const int keep = (n_tri >> 1) > 8 ? (n_tri >> 1) : 8;
             uint32_t k = kind;
@@ -1114,6 +1253,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                 remaining = popcount64(__ballot(k == OP_TRI));
                 RTK_PROF_MARK(5, 1, remaining)
             } while (remaining >= keep);
+          }
         } else if (pick == W_SHADE) {
             if (kind == OP_END) {
                 bool alive = true;
@@ -1131,7 +1271,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                     }
                 }
                 if (alive) {
-                    if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0>(L, cnt);
+                    if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0, MIXED>(L, cnt, extent);
                     else L.pc = end_pc;
                     L.kind = prog[L.pc].kind_payload & 15u;
                 }
@@ -1139,7 +1279,8 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             RTK_PROF_MARK(3, 1, n_shd)
         } else {
             if (m_oth >> lane & 1ull) {
-                step_other<real, FEAT, COUNT>(L, prog + L.pc, sc, cnt);
+                if constexpr (MIXED) step_other_mixed(L, prog + L.pc, cnt);
+                else step_other<real, FEAT, COUNT>(L, prog + L.pc, sc, cnt);
                 L.kind = prog[L.pc].kind_payload & 15u;
             }
             RTK_PROF_MARK(4, 1, n_oth)
@@ -1362,10 +1503,11 @@ static hipError_t plan_launch(Kernel kernel, int kMaxWavesPerBlock, size_t lds_b
     return hipSuccess;
 }
 
-// Bytes a workgroup stages in LDS: the traversal program followed by the material table.
+// Bytes a workgroup stages in LDS: the traversal program (MIXED or slots) followed by the material table.
 template <typename real>
-static size_t lds_image_bytes(const SceneView<real>& sc) {
-    return size_t(sc.n_slots) * sizeof(Slot<real>) + size_t(sc.n_materials) * sizeof(MaterialRec<real>);
+static size_t lds_image_bytes(const SceneView<real>& sc, bool mixed = false) {
+    const size_t program = mixed ? size_t(sc.n_units) * sizeof(MixedHead) : size_t(sc.n_slots) * sizeof(Slot<real>);
+    return program + size_t(sc.n_materials) * sizeof(MaterialRec<real>);
 }
 
 template <typename real, uint32_t FEAT, bool COUNT, bool IN_LDS>
@@ -1375,7 +1517,7 @@ static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>* c
     const int n_items = tmap.n_tiles_local * tmap.n_chunks;
     if (n_items <= 0) return hipSuccess;
     auto kernel = rtk_render_kernel<real, FEAT, COUNT, IN_LDS>;
-    const size_t lds = IN_LDS ? lds_image_bytes(sc) : 0;
+    const size_t lds = IN_LDS ? lds_image_bytes(sc, (FEAT & F_F32_BOX) != 0) : 0;
     int blocks = 0, threads = 0;
     hipError_t e = plan_launch(kernel, max_threads<real, FEAT>() / 64, lds, n_items, blocks, threads);
     if (e != hipSuccess) return e;
@@ -1386,15 +1528,23 @@ static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>* c
 }
 
 template <typename real>
-bool program_fits_lds(const SceneView<real>& sc) {
-    return lds_image_bytes(sc) <= size_t(kLdsBytesPerCU);
+bool program_fits_lds(const SceneView<real>& sc, bool mixed) {
+    return lds_image_bytes(sc, mixed) <= size_t(kLdsBytesPerCU);
 }
 
-// Kernel instantiation for a scene: the leanest feature subset that covers it, with or without the fused slab test.
-static uint32_t kernel_features(uint32_t features, bool count) {
+// The MIXED program is used whenever the upload built one (f64, sphere-only scene, fast order); variant bit 20 keeps
+// the f64 boxes instead (A/B).
+template <typename real>
+static bool use_mixed_program(const SceneView<real>& sc, uint32_t diag) {
+    return sizeof(real) == 8 && sc.program_mixed != nullptr && (diag & (1u << 20)) == 0;
+}
+
+// Kernel instantiation for a scene: the leanest feature subset that covers it, with or without the fused slab test;
+// `mixed` = the scene has a MIXED program (f64, sphere-only, fast order) and the caller did not ask for the f64 boxes.
+static uint32_t kernel_features(uint32_t features, bool count, bool mixed) {
     const uint32_t fma = features & F_FMA_BOX, scene = features & ~uint32_t(F_FMA_BOX);
     if (count) return kFeatAll | fma;
-    if (scene == kFeatLean) return kFeatLean | fma;
+    if (scene == kFeatLean) return mixed ? (kFeatLean | uint32_t(F_F32_BOX)) : (kFeatLean | fma);
     if ((scene & ~kFeatQuadBox) == 0) return kFeatQuadBox;  // no registers to spare for o*inv at 4 waves/SIMD (it spills): exact slab test, A/B on C3 40.7 vs 42.2 ms
     if ((scene & ~kFeatMesh) == 0) return kFeatMesh | fma;
     return kFeatAll | fma;
@@ -1415,10 +1565,12 @@ template <typename real>
 hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>* cam, const TileMap& tmap, uint32_t seed, uint32_t features, bool count,
                          bool allow_lds, uint32_t diag, void* partial, unsigned long long* counters, unsigned int* tile_counter,
                          const int32_t* tile_order, unsigned int* tile_cost, hipStream_t stream) {
-    const bool lds = allow_lds && program_fits_lds(sc);
+    const bool mixed = use_mixed_program(sc, diag);
+    const uint32_t feat = kernel_features(features, count, mixed);
+    const bool lds = allow_lds && program_fits_lds(sc, (feat & F_F32_BOX) != 0);
 #define RTK_LAUNCH_CASE(F) \
     case F: return launch_feat<real, F>(sc, cam, tmap, seed, count, lds, diag, partial, counters, tile_counter, tile_order, tile_cost, stream);
-    switch (kernel_features(features, count)) {
+    switch (feat) {
         RTK_LAUNCH_CASE(kFeatLean)
         RTK_LAUNCH_CASE(kFeatQuadBox)
         RTK_LAUNCH_CASE(kFeatMesh)
@@ -1426,6 +1578,10 @@ hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>* cam, 
         RTK_LAUNCH_CASE(kFeatLean | F_FMA_BOX)
         RTK_LAUNCH_CASE(kFeatMesh | F_FMA_BOX)
         RTK_LAUNCH_CASE(kFeatAll | F_FMA_BOX)
+        case kFeatLean | F_F32_BOX:
+            if constexpr (sizeof(real) == 8)
+                return launch_feat<real, kFeatLean | F_F32_BOX>(sc, cam, tmap, seed, count, lds, diag, partial, counters, tile_counter, tile_order, tile_cost, stream);
+            break;
     }
 #undef RTK_LAUNCH_CASE
     return hipErrorInvalidValue;
@@ -1434,8 +1590,8 @@ template hipError_t launch_render<double>(const SceneView<double>&, const Camera
                                           unsigned long long*, unsigned int*, const int32_t*, unsigned int*, hipStream_t);
 template hipError_t launch_render<float>(const SceneView<float>&, const CameraRec<float>*, const TileMap&, uint32_t, uint32_t, bool, bool, uint32_t, void*,
                                          unsigned long long*, unsigned int*, const int32_t*, unsigned int*, hipStream_t);
-template bool program_fits_lds<double>(const SceneView<double>&);
-template bool program_fits_lds<float>(const SceneView<float>&);
+template bool program_fits_lds<double>(const SceneView<double>&, bool);
+template bool program_fits_lds<float>(const SceneView<float>&, bool);
 
 template <typename real>
 hipError_t launch_resolve(const void* partial, const TileMap& tmap, int width, int height, double samples_scale, void* out_linear, uint8_t* out_rgb8,
@@ -1472,9 +1628,9 @@ hipError_t launch_unpermute(const void* gathered, int width, int height, int n_r
 template hipError_t launch_unpermute<double>(const void*, int, int, int, long long, void*, uint8_t*, hipStream_t);
 template hipError_t launch_unpermute<float>(const void*, int, int, int, long long, void*, uint8_t*, hipStream_t);
 
-const char* render_kernel_name(bool f64, uint32_t features, bool count, bool lds) {
+const char* render_kernel_name(bool f64, uint32_t features, bool count, bool lds, bool mixed) {
     static thread_local char name[96];
-    snprintf(name, sizeof name, "rtk_render_kernel<%s, %uu, %s, %s>", f64 ? "double" : "float", kernel_features(features, count), count ? "true" : "false",
+    snprintf(name, sizeof name, "rtk_render_kernel<%s, %uu, %s, %s>", f64 ? "double" : "float", kernel_features(features, count, mixed && f64), count ? "true" : "false",
              (lds && !count) ? "true" : "false");
     return name;
 }

@@ -309,7 +309,7 @@ def test_fast_order_on_the_device(rt, orc, renderer, scenes, case):
     info = renderer.upload_fast(scene, cam.center)
     assert info["exact"] == fast.exact
     feat = int(renderer.kernel_name().split(",")[1].strip().rstrip("u"))
-    assert (feat & 128) or feat == 69   # the fused-slab instantiation (the quad/box subset kernel keeps the exact test)
+    assert (feat & 128) or feat == 256 or feat == 69   # fused slab test / MIXED program (sphere-only scenes) / the quad-box subset kernel keeps the exact test
     fused, fused8, fcnt = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, count=True)
     fused_fast, _, _ = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64)
     assert np.array_equal(fused, gpu) and np.array_equal(fused8, gpu8) and np.array_equal(fused_fast, gpu) and fcnt == counters
@@ -346,3 +346,70 @@ def test_fast_order_full_resolution_book1_is_bit_identical_and_cheaper(rt, rende
     assert torch.equal(a, b) and torch.equal(a8, b8)
     assert ca["rng_draws"] == cb["rng_draws"] and ca["segments"] == cb["segments"] and ca["surface_hits"] == cb["surface_hits"]
     assert cb["box_tests"] < 0.6 * ca["box_tests"] and cb["sphere_tests"] < ca["sphere_tests"]
+
+
+# ---- the MIXED program: f32 culling boxes + exact f64 spheres (F_F32_BOX kernels) ---------------------------------
+class _SphereRec(__import__("ctypes").Structure):
+    import ctypes as _C
+    _fields_ = [("center0", _C.c_double * 3), ("center_dir", _C.c_double * 3), ("radius", _C.c_double), ("material", _C.c_int32), ("_pad", _C.c_int32)]
+
+
+def _spheres_of(scene):
+    """The rtk_sphere table of a flattened scene (include/rtk.h), writable: tests poke motion into it."""
+    import ctypes as C
+
+    from tests.test_fast_order import DescHead
+
+    head = DescHead.from_address(scene.desc_ptr)
+    base = scene.desc_ptr + DescHead.list_children.offset + C.sizeof(C.c_void_p)   # `spheres` follows `list_children`
+    ptr = C.c_void_p.from_address(base).value
+    return (_SphereRec * head.n_spheres).from_address(ptr)
+
+
+def test_mixed_program_kernel_is_used_and_bit_identical(rt, orc, renderer, scenes):
+    """Sphere-only scenes in the fast order run the F_F32_BOX kernel (feature word 256): conservative f32 boxes must
+    not change a single bit of the image; variant bit 20 falls back to the f64 fused boxes with the same result."""
+    scene = scenes("book1_final")
+    cam = scene.camera(256, 144, 16, 50)
+    renderer.upload(scene)
+    base, base8, _ = renderer.render_host(cam)
+    renderer.upload_fast(scene, cam.center)
+    assert "double, 256u" in renderer.kernel_name() and "double, 128u" in renderer.kernel_name(variant=1 << 20)
+    mixed, mixed8, _ = renderer.render_host(cam)
+    fused, fused8, _ = renderer.render_host(cam, variant=1 << 20)
+    in_global, _, _ = renderer.render_host(cam, variant=1)
+    assert np.array_equal(mixed, base) and np.array_equal(mixed8, base8)
+    assert np.array_equal(fused, base) and np.array_equal(in_global, base)
+    ref, ref8, _ = orc.render(scene.desc_ptr, cam, RENDER_SEED, 8)
+    assert rmse(mixed, ref) < F64_RMSE_BOUND and np.array_equal(mixed8, ref8)
+
+
+def test_mixed_program_moving_spheres_and_far_cameras(rt, orc, renderer):
+    """Moving spheres (3-unit records) and rays the f32 test must not judge: a camera far outside the coordinate bound
+    the box margin was sized for sends every primary ray through the exact f64 test on the f32 bounds."""
+    scene = rt.Scene.build("three_spheres", SCENE_SEED)
+    spheres = _spheres_of(scene)
+    spheres[1].center_dir[0], spheres[1].center_dir[1] = 0.3, 0.2        # the centre sphere now moves (sphere.h:20-28)
+    spheres[3].center_dir[2] = -0.25
+    cam = scene.camera(96, 54, 8, 10)
+    # The motion was poked in after the reference's bvh_node boxes were computed, so the reference order is not the
+    # yardstick here: the optimiser recomputes every box from the primitives (sphere.h:24-26), and the oracle and the
+    # exact-slab kernels run on that hierarchy.
+    fast = scene.fast_order(cam.center)
+    ref, ref8, _ = orc.render(fast.desc_ptr, cam, RENDER_SEED, 4)
+    renderer.upload(fast)
+    base, base8, _ = renderer.render_host(cam)
+    assert rmse(base, ref) < F64_RMSE_BOUND and np.array_equal(base8, ref8)
+    renderer.upload_fast(scene, cam.center)
+    assert "double, 256u" in renderer.kernel_name()
+    mixed, mixed8, _ = renderer.render_host(cam)
+    assert np.array_equal(mixed, base) and np.array_equal(mixed8, base8)
+    # a camera 700 units away along +z (the scene spans ~200): no eye passed, so the margin ignores it
+    far = scene.camera(96, 54, 8, 10)
+    for v in (far.center, far.pixel00_loc):
+        v.z += 700.0
+    ref_far, _, _ = orc.render(fast.desc_ptr, far, RENDER_SEED, 4)
+    renderer.upload_fast(scene, None)
+    got_far, _, _ = renderer.render_host(far)
+    assert rmse(got_far, ref_far) < F64_RMSE_BOUND
+    assert got_far.std() > 0.01   # the far camera still sees the scene

@@ -2,7 +2,7 @@
 -DRTK_PROFILE (s_memtime stamps at the scheduler's phase boundaries), renders one frame and prints,
 per phase: share of wave-cycles, steps, cycles per step, mean active lanes.  Tools only.
 
-  python3 tools/profile_phases.py [config=c2] [real=f64] [spp=0] [order=auto|reference|fast]
+  python3 tools/profile_phases.py [config=c2] [real=f64] [spp=0] [order=auto|reference|fast] [variant=0]
 """
 import os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,6 +21,7 @@ config = sys.argv[1] if len(sys.argv) > 1 else "c2"
 real = rt.RTK_REAL_F64 if (len(sys.argv) <= 2 or sys.argv[2] == "f64") else rt.RTK_REAL_F32
 spp = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 order = sys.argv[4] if len(sys.argv) > 4 else "auto"
+variant = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 tmp = tempfile.mkdtemp()
 earth = rt.write_synthetic_earth(os.path.join(tmp, "earth_synth.ppm"))
 scene = rt.Scene.build(rt.CONFIG_SCENES[config], rt.SCENE_SEED, earth)
@@ -37,7 +38,7 @@ prof = torch.zeros(18, dtype=torch.int64, device=dev)
 # the profile build writes its counters through the d_counters pointer of the (non-counting) kernel
 lib = rt.hip_lib()
 import ctypes as C
-opts = rt.RenderOpts(rt.RENDER_SEED, real, 0, 1, 0, 0, torch.cuda.current_stream().cuda_stream)
+opts = rt.RenderOpts(rt.RENDER_SEED, real, 0, 1, 0, variant, torch.cuda.current_stream().cuda_stream)
 for k in range(2):
     prof.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -576,6 +576,12 @@ struct rtk_ctx {
     int order_shape[5] = {0, 0, 0, 0, 0};  // width, height, rank, n_ranks, tiles: what the stored order was measured on
     std::vector<CameraRec<double>> h_cameras64;
     std::vector<CameraRec<float>> h_cameras32;
+    // The camera of the previous launch per arithmetic type: a frame loop renders the same camera again and again, and
+    // re-sending 256 bytes through a pageable-memory copy costs a host/stream round trip per frame for nothing.
+    unsigned int next_camera = 0;
+    bool cam_valid[2] = {false, false};
+    rtk_camera cam_last[2];
+    unsigned int cam_slot[2] = {0, 0};
 };
 constexpr unsigned int kCounterRing = 256;
 constexpr size_t kCameraStride = 256;
@@ -756,19 +762,34 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
     unsigned int* tile_cost = learn ? ctx->d_tile_cost : nullptr;
     const unsigned int slot = ctx->next_counter++ % kCounterRing;
     unsigned int* tile_counter = ctx->tile_counters + slot;
-    unsigned char* d_cam = ctx->d_cameras + slot * kCameraStride;
+    const int cam_mode = opts->real_mode == RTK_REAL_F64 ? 0 : 1;
+    const bool cam_cached = ctx->cam_valid[cam_mode] && std::memcmp(&ctx->cam_last[cam_mode], cam, sizeof(rtk_camera)) == 0;
+    const unsigned int cslot = cam_cached ? ctx->cam_slot[cam_mode] : (ctx->next_camera++ % kCounterRing);
+    if (!cam_cached) {
+        // a slot about to be overwritten may still be the other mode's cached camera
+        for (int m = 0; m < 2; m++)
+            if (ctx->cam_valid[m] && ctx->cam_slot[m] == cslot) ctx->cam_valid[m] = false;
+        ctx->cam_last[cam_mode] = *cam;
+        ctx->cam_slot[cam_mode] = cslot;
+        ctx->cam_valid[cam_mode] = true;
+    }
+    unsigned char* d_cam = ctx->d_cameras + cslot * kCameraStride;
     const bool allow_lds = (opts->variant & 1) == 0;  // variant bit 0: keep the program in global memory (A/B)
     const uint32_t diag = uint32_t(opts->variant) & 0x1FFF00u;  // bits 8..20: scheduler policy / program layout A/B used by tools/ only
     hipError_t e;
     if (opts->real_mode == RTK_REAL_F64) {
-        ctx->h_cameras64[slot] = to_device_camera<double>(*cam);
-        RTK_HIP(hipMemcpyAsync(d_cam, &ctx->h_cameras64[slot], sizeof(CameraRec<double>), hipMemcpyHostToDevice, stream));
+        if (!cam_cached) {
+            ctx->h_cameras64[cslot] = to_device_camera<double>(*cam);
+            RTK_HIP(hipMemcpyAsync(d_cam, &ctx->h_cameras64[cslot], sizeof(CameraRec<double>), hipMemcpyHostToDevice, stream));
+        }
         e = launch_render<double>(ctx->scene64.view, reinterpret_cast<const CameraRec<double>*>(d_cam), tm, opts->seed, ctx->features,
                                   opts->count_work != 0, allow_lds, diag, ctx->d_partial, counters, tile_counter, tile_order, tile_cost, stream);
         if (e == hipSuccess) e = launch_resolve<double>(ctx->d_partial, tm, cam->image_width, cam->image_height, cam->pixel_samples_scale, d_linear, d_rgb8, stream);
     } else {
-        ctx->h_cameras32[slot] = to_device_camera<float>(*cam);
-        RTK_HIP(hipMemcpyAsync(d_cam, &ctx->h_cameras32[slot], sizeof(CameraRec<float>), hipMemcpyHostToDevice, stream));
+        if (!cam_cached) {
+            ctx->h_cameras32[cslot] = to_device_camera<float>(*cam);
+            RTK_HIP(hipMemcpyAsync(d_cam, &ctx->h_cameras32[cslot], sizeof(CameraRec<float>), hipMemcpyHostToDevice, stream));
+        }
         e = launch_render<float>(ctx->scene32.view, reinterpret_cast<const CameraRec<float>*>(d_cam), tm, opts->seed, ctx->features,
                                  opts->count_work != 0, allow_lds, diag, ctx->d_partial, counters, tile_counter, tile_order, tile_cost, stream);
         if (e == hipSuccess) e = launch_resolve<float>(ctx->d_partial, tm, cam->image_width, cam->image_height, cam->pixel_samples_scale, d_linear, d_rgb8, stream);

@@ -530,6 +530,21 @@ int rtk_scene_optimize(const rtk_scene_desc* scene, const rtk_optimize_opts* opt
         h->children.push_back(root);
         root = op.push_node(RTK_NODE_LIST, first, 1, 0);
     }
+    // The root box holds the whole scene.  Every secondary ray starts on a surface, i.e. inside it, and so does every
+    // primary ray when the eye lies inside it: a slab test from the inside cannot fail (the interval starts at 0.001,
+    // Camera.txt:211), so the root's test is dropped -- its two children are visited unconditionally, in order.
+    if (h->nodes[size_t(root)].kind == RTK_NODE_BVH && opts.has_eye) {
+        const rtk_node rn = h->nodes[size_t(root)];
+        const rtk_aabb& rb = h->boxes[size_t(rn.c)];
+        const bool inside = opts.eye.x > rb.xmin && opts.eye.x < rb.xmax && opts.eye.y > rb.ymin && opts.eye.y < rb.ymax && opts.eye.z > rb.zmin &&
+                            opts.eye.z < rb.zmax;
+        if (inside) {
+            const int32_t first = int32_t(h->children.size());
+            h->children.push_back(rn.a);
+            h->children.push_back(rn.b);
+            root = op.push_node(RTK_NODE_LIST, first, 2, 0);
+        }
+    }
     h->desc = *scene;  // primitive, material, texture, image, perlin and light tables are borrowed from the input
     h->desc.root = root;
     h->desc.n_nodes = int32_t(h->nodes.size());

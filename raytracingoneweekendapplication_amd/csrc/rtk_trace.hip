@@ -1056,7 +1056,8 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
     constexpr int kRefillMinTable[8] = {8, 1, 4, 8, 16, 24, 32, 12};
     const int refill_min = kRefillMinTable[(diag >> 14) & 7];
     constexpr int kSphereMinTable[8] = {16, 65, 4, 8, 12, 16, 24, 32};  // variant bits 17..19; 65 = never (spheres only through the vote)
-    const int sphere_min = kSphereMinTable[(diag >> 17) & 7];
+    const int sphere_sel = int(diag >> 17) & 7;
+    const int sphere_min = (sphere_sel == 0 && (FEAT & F_F32_BOX)) ? 12 : kSphereMinTable[sphere_sel];  // the MIXED kernel's sweet spot is 12 (24.5 vs 24.7 ms)
 
     Lane<real> L;
     L.pc = end_pc;
@@ -1161,6 +1162,13 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             const int eighths = sel == 0 ? 2 : sel;  // measured on C2 (votes now cost ~2 box steps, spheres ride along): 2/8 of the starters 30.9 ms, 3/8 31.8, 4/8 32.4
             const int frac = (n_box * eighths) >> 3;
             const int keep = frac > 8 ? frac : 8;
+            // Box steps per trip around the loop's scalar checks.  Measured per kernel (tools/ab): the MIXED sphere kernel
+            // (long runs of cheap box steps) 27.8 / 26.3 / 25.5 / 24.8 / 24.6 ms at 1 / 2 / 4 / 6 / 8; the reference-order
+            // kernels lose with any unrolling (C2 53.2 -> 54.8 at 4; C4 62.6 -> 64.2), the full-feature kernel gains 1 % at 2.
+#ifndef RTK_UNROLL_MIXED
+#define RTK_UNROLL_MIXED 8
+#endif
+            constexpr int kBoxUnroll = MIXED ? RTK_UNROLL_MIXED : ((FEAT & ~uint32_t(F_FMA_BOX)) == kFeatAll ? 2 : 1);
             ProgRec cur = prog[L.pc];  // the record at L.pc (its first 32 bytes in the MIXED layout), held in registers: one LDS round trip per step
             uint32_t k = kind;
             const uint32_t box_kind = L.box_kind;  // a lane with an irregular ray matches nothing here: it never steps in this loop
@@ -1176,6 +1184,18 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                     cur = prog[L.pc];
                     k = cur.kind_payload & 15u;
                     L.kind = k;
+                }
+#pragma unroll
+                for (int extra = 1; extra < kBoxUnroll; extra++) {
+                    // further box steps before the loop's scalar checks (vote / sphere / exit): the checks are a
+                    // dependent v_cmp -> s_bcnt1 -> s_cmp -> branch chain per step, and the kernel is latency-bound
+                    if (k == box_kind) {
+                        if constexpr (MIXED) step_box32(L, cur, cnt);
+                        else step_box<false, (FEAT & F_XFORM) != 0, (FEAT & F_FMA_BOX) != 0>(L, cur, cnt);
+                        cur = prog[L.pc];
+                        k = cur.kind_payload & 15u;
+                        L.kind = k;
+                    }
                 }
                 if (popcount64(__ballot(k == OP_SPHERE)) >= sphere_min) {
                     if (k == OP_SPHERE) {

@@ -709,6 +709,8 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
     tm.n_ranks = opts->n_ranks;
     tm.n_tiles_local = int32_t(rtk_tiles_per_rank(cam->image_width, cam->image_height, opts->n_ranks));
     tm.compact = opts->n_ranks > 1 ? 1 : 0;
+    tm.order_in_lds = 0;
+    tm.order_lds_offset = 0;
     // Split every pixel's samples into chunks of 4 (at most 64 chunks) so that no lane is stuck with a whole
     // heavy pixel: a glass pixel's samples cost ~0.5 ms each, and the largest (pixel, chunk) bounds the end of
     // the frame whatever the GPU count.  Measured on C2 (kernel time, N = 1 / one of 8 shards): 8-sample chunks

@@ -192,6 +192,8 @@ struct TileMap {  // which tiles this launch renders and where the pixels go
     // the resolve kernel adds a pixel's chunks in index order.
     int32_t n_chunks;
     int16_t chunk_start[kMaxChunks + 1];
+    // set by the launcher: the tile hand-out order is staged in LDS at this byte offset of the dynamic segment
+    int32_t order_in_lds, order_lds_offset;
 };
 
 // Indices into the uint64 work-counter block (same order as rtk_work_counters).

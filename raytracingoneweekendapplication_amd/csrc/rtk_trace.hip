@@ -1030,6 +1030,15 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
         prog = reinterpret_cast<const ProgRec*>(lds_program);
         mats = reinterpret_cast<const MaterialRec<real>*>(lds_program + size_t(n_prog16) * 16);
     }
+    // The hand-out order of the tiles (learned from the previous frame) is staged behind the program when the host
+    // found room for it (tmap.order_in_lds): a lookup per work item from LDS instead of a cold global load.
+    const int32_t* lds_order = nullptr;
+    if (tmap.order_in_lds && tile_order) {
+        int32_t* dst_order = reinterpret_cast<int32_t*>(lds_program + tmap.order_lds_offset);
+        for (int k = threadIdx.x; k < tmap.n_tiles_local; k += blockDim.x) dst_order[k] = tile_order[k];
+        __syncthreads();
+        lds_order = dst_order;
+    }
     // The camera lives in device memory and is read with scalar loads where it is
     // used (once per sample); as a by-value argument it would sit in registers for
     // the whole kernel.
@@ -1072,6 +1081,11 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
     // samples); when the item is used up the wave first pulls another one from the rank-wide counter.  A (pixel,
     // chunk) belongs to exactly one lane, which walks its samples in order.  Returns true when idle lanes remain that
     // were not offered a pixel (the item ran out first).  Everything that steers it is wave-uniform.
+    // What is the same for all 64 pixels of a work item is computed when the item is taken, on the scalar unit: the
+    // integer divisions that turn the item index into (tile, chunk, pixel origin) and the tile_order lookup used to be
+    // redone -- and their latencies waited for -- in every refill round (~12 lanes each, 4.3 M rounds per C2 frame).
+    int it_x0 = 0, it_y0 = 0, it_slot = 0, it_s_begin = 0, it_s_end = 0, it_cost_tile = -1;
+    bool it_ok = false;
     auto hand_out = [&](unsigned long long m_idle) -> bool {
         if (refill_next >= 64) {
             const int t = int(__builtin_amdgcn_readfirstlane(prefetched_item));
@@ -1082,26 +1096,33 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             refill_item = t;
             refill_next = 0;
             if (lane == 0) prefetched_item = atomicAdd(tile_counter, 1u);
+            // Items are handed out in `tile_order` when the host has one (most expensive tiles of the previous
+            // frame first); which wave renders a tile, and when, never changes a pixel's value.
+            const int position = t / tmap.n_chunks, chunk = t % tmap.n_chunks;
+            int local_tile = position;
+            if (tile_order) local_tile = lds_order ? int(__builtin_amdgcn_readfirstlane(lds_order[position])) : tile_order[position];
+            const int tile = local_tile * tmap.n_ranks + tmap.rank;
+            it_slot = chunk * tmap.n_tiles_local + local_tile;
+            it_x0 = (tile % tmap.tiles_x) * 8;
+            it_y0 = (tile / tmap.tiles_x) * 8;
+            it_s_begin = tmap.chunk_start[chunk];
+            it_s_end = tmap.chunk_start[chunk + 1];
+            it_cost_tile = chunk == 0 ? local_tile : -1;  // chunk 0 of every pixel reports the tile's cost
+            it_ok = tile < n_tiles_total && it_s_begin < it_s_end;
         }
         const int avail = 64 - refill_next;
         const int rank_in_idle = int(__builtin_amdgcn_mbcnt_hi(uint32_t(m_idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m_idle), 0u)));
         if (L.kind == OP_DEAD && rank_in_idle < avail) {
             my_pix = refill_next + rank_in_idle;
-            // Items are handed out in `tile_order` when the host has one (most expensive tiles of the previous
-            // frame first); which wave renders a tile, and when, never changes a pixel's value.
-            const int position = refill_item / tmap.n_chunks, chunk = refill_item % tmap.n_chunks;
-            const int local_tile = tile_order ? tile_order[position] : position;
-            const int tile = local_tile * tmap.n_ranks + tmap.rank;
-            my_slot = chunk * tmap.n_tiles_local + local_tile;
-            px_i = (tile % tmap.tiles_x) * 8 + (my_pix & 7);
-            px_j = (tile / tmap.tiles_x) * 8 + (my_pix >> 3);
-            const int s_begin = tmap.chunk_start[chunk];
-            s_end = tmap.chunk_start[chunk + 1];
-            if (tile < n_tiles_total && px_i < width && px_j < height && s_begin < s_end) {
+            my_slot = it_slot;
+            px_i = it_x0 + (my_pix & 7);
+            px_j = it_y0 + (my_pix >> 3);
+            s_end = it_s_end;
+            if (it_ok && px_i < width && px_j < height) {
                 L.sum = mk(real(0), real(0), real(0));
-                L.s = s_begin;
+                L.s = it_s_begin;
                 L.segs = 0;
-                cost_tile = chunk == 0 ? local_tile : -1;  // chunk 0 of every pixel reports the tile's cost
+                cost_tile = it_cost_tile;
                 begin_sample(L, cam, px_i, px_j, seed_hash, cnt);
                 if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0, MIXED>(L, cnt, extent);
                 else L.pc = end_pc;  // max_depth == 0: ray_color returns black at once (Camera.txt:205-206)
@@ -1123,7 +1144,9 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             const unsigned long long m_idle = __ballot(L.kind == OP_DEAD);
             const int n_idle = popcount64(m_idle);
             if (uniform(!exhausted && (n_idle >= refill_min || n_idle == 64))) {
+                RTK_PROF_MARK(0, 0, 0)
                 if (uniform(hand_out(m_idle))) hand_out(__ballot(L.kind == OP_DEAD));
+                RTK_PROF_MARK(4, 1, n_idle)  // profile build: refills are booked under "other op" (phase 4)
             }
         }
 
@@ -1537,13 +1560,23 @@ static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>* c
     const int n_items = tmap.n_tiles_local * tmap.n_chunks;
     if (n_items <= 0) return hipSuccess;
     auto kernel = rtk_render_kernel<real, FEAT, COUNT, IN_LDS>;
-    const size_t lds = IN_LDS ? lds_image_bytes(sc, (FEAT & F_F32_BOX) != 0) : 0;
+    size_t lds = IN_LDS ? lds_image_bytes(sc, (FEAT & F_F32_BOX) != 0) : 0;
+    // room for the tile order behind the program?  (never at the price of a second resident workgroup's LDS)
+    TileMap tm = tmap;
+    tm.order_in_lds = 0;
+    tm.order_lds_offset = int32_t((lds + 15) & ~size_t(15));
+    const size_t order_bytes = size_t(tmap.n_tiles_local) * sizeof(int32_t);
+    if (tile_order && size_t(tm.order_lds_offset) + order_bytes <= size_t(kLdsBytesPerCU) &&
+        (lds == 0 || kLdsBytesPerCU / lds == kLdsBytesPerCU / (size_t(tm.order_lds_offset) + order_bytes))) {
+        tm.order_in_lds = 1;
+        lds = size_t(tm.order_lds_offset) + order_bytes;
+    }
     int blocks = 0, threads = 0;
     hipError_t e = plan_launch(kernel, max_threads<real, FEAT>() / 64, lds, n_items, blocks, threads);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(tile_counter, 0, sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
-    kernel<<<dim3(blocks), dim3(threads), lds, stream>>>(sc, cam, tmap, seed, static_cast<real*>(partial), counters, tile_counter, tile_order, tile_cost, diag);
+    kernel<<<dim3(blocks), dim3(threads), lds, stream>>>(sc, cam, tm, seed, static_cast<real*>(partial), counters, tile_counter, tile_order, tile_cost, diag);
     return hipGetLastError();
 }
 

@@ -1,0 +1,159 @@
+"""A ctypes mirror of rtk_scene_desc (include/rtk.h) and a small builder, so that tests can hand the C ABI, the
+optimiser and the oracle scenes that no named scene of scene_library.h covers (random soups, odd graphs)."""
+import ctypes as C
+import math
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("z", C.c_double)]
+
+
+class Node(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_int32)]
+
+
+class Sphere(C.Structure):
+    _fields_ = [("center0", Vec3), ("center_dir", Vec3), ("radius", C.c_double), ("material", C.c_int32), ("_pad", C.c_int32)]
+
+
+class Quad(C.Structure):
+    _fields_ = [("Q", Vec3), ("u", Vec3), ("v", Vec3), ("w", Vec3), ("normal", Vec3), ("D", C.c_double), ("material", C.c_int32), ("_pad", C.c_int32)]
+
+
+class Triangle(C.Structure):
+    _fields_ = [("p0", Vec3), ("p1", Vec3), ("p2", Vec3), ("normal", Vec3), ("uv0", C.c_float * 2), ("uv1", C.c_float * 2), ("uv2", C.c_float * 2),
+                ("material", C.c_int32), ("_pad", C.c_int32)]
+
+
+class Aabb(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax")]
+
+
+class Translate(C.Structure):
+    _fields_ = [("offset", Vec3)]
+
+
+class RotateY(C.Structure):
+    _fields_ = [("sin_theta", C.c_double), ("cos_theta", C.c_double)]
+
+
+class Medium(C.Structure):
+    _fields_ = [("neg_inv_density", C.c_double), ("material", C.c_int32), ("_pad", C.c_int32)]
+
+
+class Material(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("texture", C.c_int32), ("albedo", Vec3), ("param", C.c_double)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("even", C.c_int32), ("odd", C.c_int32), ("image", C.c_int32), ("color", Vec3), ("param", C.c_double)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("root", C.c_int32), ("n_nodes", C.c_int32), ("n_list_children", C.c_int32), ("n_spheres", C.c_int32),
+                ("n_quads", C.c_int32), ("n_triangles", C.c_int32), ("n_bvh_boxes", C.c_int32), ("n_translates", C.c_int32), ("n_rotates", C.c_int32),
+                ("n_media", C.c_int32), ("n_materials", C.c_int32), ("n_textures", C.c_int32), ("n_images", C.c_int32), ("n_perlins", C.c_int32),
+                ("n_lights", C.c_int32), ("n_texel_bytes", C.c_int64),
+                ("nodes", C.POINTER(Node)), ("list_children", C.POINTER(C.c_int32)), ("spheres", C.POINTER(Sphere)), ("quads", C.POINTER(Quad)),
+                ("triangles", C.POINTER(Triangle)), ("bvh_boxes", C.POINTER(Aabb)), ("translates", C.POINTER(Translate)), ("rotates", C.POINTER(RotateY)),
+                ("media", C.POINTER(Medium)), ("materials", C.POINTER(Material)), ("textures", C.POINTER(Texture)), ("images", C.c_void_p),
+                ("texels", C.c_void_p), ("perlins", C.c_void_p), ("lights", C.c_void_p)]
+
+
+NODE_SPHERE, NODE_QUAD, NODE_TRIANGLE, NODE_LIST, NODE_BVH, NODE_TRANSLATE, NODE_ROTATE_Y, NODE_MEDIUM = range(1, 9)
+MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC, MAT_SPECULAR = range(1, 7)
+TEX_SOLID = 1
+
+
+def _cross(a, b):
+    return (a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0])
+
+
+def _dot(a, b):
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]
+
+
+class DescBuilder:
+    """Collects nodes and tables; `finish(root)` returns an object whose `.desc_ptr` is a valid rtk_scene_desc* (kept alive by it)."""
+
+    def __init__(self):
+        self.nodes, self.children, self.spheres, self.quads, self.translates, self.rotates, self.media = [], [], [], [], [], [], []
+        self.materials, self.textures = [], []
+
+    def _node(self, kind, a=0, b=0, c=0):
+        self.nodes.append(Node(kind, a, b, c))
+        return len(self.nodes) - 1
+
+    def solid(self, rgb):
+        self.textures.append(Texture(TEX_SOLID, 0, 0, 0, Vec3(*rgb), 0.0))
+        return len(self.textures) - 1
+
+    def lambertian(self, rgb):
+        self.materials.append(Material(MAT_LAMBERTIAN, self.solid(rgb), Vec3(0, 0, 0), 0.0))
+        return len(self.materials) - 1
+
+    def metal(self, rgb, fuzz):
+        self.materials.append(Material(MAT_METAL, -1, Vec3(*rgb), min(fuzz, 1.0)))
+        return len(self.materials) - 1
+
+    def dielectric(self, index):
+        self.materials.append(Material(MAT_DIELECTRIC, -1, Vec3(0, 0, 0), index))
+        return len(self.materials) - 1
+
+    def light(self, rgb):
+        self.materials.append(Material(MAT_DIFFUSE_LIGHT, self.solid(rgb), Vec3(0, 0, 0), 0.0))
+        return len(self.materials) - 1
+
+    def sphere(self, centre, radius, material, motion=(0.0, 0.0, 0.0)):
+        self.spheres.append(Sphere(Vec3(*centre), Vec3(*motion), max(0.0, radius), material, 0))
+        return self._node(NODE_SPHERE, len(self.spheres) - 1)
+
+    def quad(self, Q, u, v, material):
+        n = _cross(u, v)                                   # quad.h:12-19
+        nn = _dot(n, n)
+        length = math.sqrt(nn)
+        normal = tuple((1 / length) * c for c in n)        # unit_vector: v / length = (1/length) * v (vec3.h:91-93,104-106)
+        w = tuple((1 / nn) * c for c in n)                 # n / dot(n, n)
+        self.quads.append(Quad(Vec3(*Q), Vec3(*u), Vec3(*v), Vec3(*w), Vec3(*normal), _dot(normal, Q), material, 0))
+        return self._node(NODE_QUAD, len(self.quads) - 1)
+
+    def list(self, members):
+        first = len(self.children)
+        self.children.extend(members)
+        return self._node(NODE_LIST, first, len(members))
+
+    def translate(self, child, offset):
+        self.translates.append(Translate(Vec3(*offset)))
+        return self._node(NODE_TRANSLATE, len(self.translates) - 1, child)
+
+    def rotate_y(self, child, degrees):
+        r = degrees * 3.1415926535897932385 / 180.0        # rtweekend.h:21-23
+        self.rotates.append(RotateY(math.sin(r), math.cos(r)))
+        return self._node(NODE_ROTATE_Y, len(self.rotates) - 1, child)
+
+    def finish(self, root):
+        return BuiltDesc(self, root)
+
+
+class BuiltDesc:
+    def __init__(self, b, root):
+        def arr(ctype, items):
+            a = (ctype * max(1, len(items)))(*items)
+            return a
+        self._keep = dict(nodes=arr(Node, b.nodes), children=(C.c_int32 * max(1, len(b.children)))(*b.children), spheres=arr(Sphere, b.spheres),
+                          quads=arr(Quad, b.quads), translates=arr(Translate, b.translates), rotates=arr(RotateY, b.rotates), media=arr(Medium, b.media),
+                          materials=arr(Material, b.materials), textures=arr(Texture, b.textures), tris=arr(Triangle, []), boxes=arr(Aabb, []))
+        k = self._keep
+        d = SceneDesc()
+        d.abi_version, d.root = 1, root
+        d.n_nodes, d.n_list_children, d.n_spheres, d.n_quads = len(b.nodes), len(b.children), len(b.spheres), len(b.quads)
+        d.n_translates, d.n_rotates, d.n_media, d.n_materials, d.n_textures = len(b.translates), len(b.rotates), len(b.media), len(b.materials), len(b.textures)
+        d.nodes, d.list_children, d.spheres, d.quads = k["nodes"], k["children"], k["spheres"], k["quads"]
+        d.triangles, d.bvh_boxes, d.translates, d.rotates = k["tris"], k["boxes"], k["translates"], k["rotates"]
+        d.media, d.materials, d.textures = k["media"], k["materials"], k["textures"]
+        self.desc = d
+        self.name = "built"
+
+    @property
+    def desc_ptr(self):
+        return C.addressof(self.desc)

@@ -1,0 +1,71 @@
+"""CPU property test of rtk_scene_optimize on random scenes that scene_library.h does not cover: soups of spheres
+(static and moving) and quads, nested lists, rotate_y/translate instances of sub-lists, metal / glass / lambertian / light
+materials.  The reference order here is the plainest possible -- a flat hittable_list tests every object for every ray
+(hittable_list.h:22-35), no box in sight -- so the oracle's image of it is ground truth for the closest hits, and the
+oracle's image of the optimised hierarchy (SAH boxes recomputed from the primitives, rotated instance boxes, margins,
+boxless runs, dropped root box) must equal it bit for bit."""
+import ctypes as C
+import math
+import random
+
+import numpy as np
+import pytest
+
+from tests.desc_builder import DescBuilder
+
+
+def random_scene(seed):
+    rnd = random.Random(seed)
+    b = DescBuilder()
+    mats = [b.lambertian((rnd.random(), rnd.random(), rnd.random())) for _ in range(3)]
+    mats += [b.metal((0.8, 0.7, 0.6), rnd.random() * 0.4), b.dielectric(1.5), b.light((4.0, 4.0, 3.5))]
+
+    def prim():
+        m = rnd.choice(mats)
+        if rnd.random() < 0.65:
+            c = (rnd.uniform(-4, 4), rnd.uniform(-1, 3), rnd.uniform(-8, -2))
+            motion = (rnd.uniform(-0.3, 0.3), rnd.uniform(-0.2, 0.2), 0.0) if rnd.random() < 0.25 else (0.0, 0.0, 0.0)
+            return b.sphere(c, rnd.uniform(0.15, 0.9), m, motion)
+        q = (rnd.uniform(-4, 3), rnd.uniform(-1, 2), rnd.uniform(-8, -3))
+        u = (rnd.uniform(0.3, 1.5), rnd.uniform(-0.3, 0.3), rnd.uniform(-0.5, 0.5))
+        v = (rnd.uniform(-0.3, 0.3), rnd.uniform(0.3, 1.5), rnd.uniform(-0.5, 0.5))
+        return b.quad(q, u, v, m)
+
+    top = [b.sphere((0, -101, -5), 100.0, mats[0])]           # a ground sphere: one huge box among small ones
+    for _ in range(rnd.randint(6, 14)):
+        top.append(prim())
+    for _ in range(rnd.randint(1, 3)):                        # instances of small sub-lists
+        sub = b.list([prim() for _ in range(rnd.randint(1, 4))])
+        inst = sub
+        if rnd.random() < 0.7:
+            inst = b.rotate_y(inst, rnd.uniform(-40, 40))
+        if rnd.random() < 0.8:
+            inst = b.translate(inst, (rnd.uniform(-1, 1), rnd.uniform(-0.5, 0.5), rnd.uniform(-1, 1)))
+        if rnd.random() < 0.3:
+            inst = b.rotate_y(inst, rnd.uniform(-20, 20))   # two rotations around a translation
+        top.append(inst)
+    if rnd.random() < 0.5:                                   # a nested list, and the same object listed twice
+        top.append(b.list([prim(), top[1]]))
+    rnd.shuffle(top)
+    return b.finish(b.list(top))
+
+
+def look_at_camera(rt):
+    cam = rt.Scene.build("three_spheres").camera(48, 27, 3, 6)   # at the origin, looking down -z: the soup lies in front of it
+    return cam
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_soups_render_identically_in_the_fast_order(rt, orc, seed):
+    scene = random_scene(1000 + seed)
+    cam = look_at_camera(rt)
+    ref, ref8, rc = orc.render(scene.desc_ptr, cam, 7, 4)
+    for eye in (cam.center, None):
+        fast = rt.FastOrderScene(scene, eye)
+        assert fast.exact
+        got, got8, gc = orc.render(fast.desc_ptr, cam, 7, 4)
+        assert np.array_equal(got, ref) and np.array_equal(got8, ref8), f"seed {seed}: max diff {np.abs(got - ref).max()}"
+        for k in ("segments", "surface_hits", "rng_draws"):
+            assert gc[k] == rc[k], k
+        assert gc["box_tests"] > 0 and gc["sphere_tests"] + gc["quad_tests"] < rc["sphere_tests"] + rc["quad_tests"]
+    assert ref.std() > 0.01   # the camera actually sees the soup

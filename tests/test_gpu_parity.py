@@ -413,3 +413,21 @@ def test_mixed_program_moving_spheres_and_far_cameras(rt, orc, renderer):
     got_far, _, _ = renderer.render_host(far)
     assert rmse(got_far, ref_far) < F64_RMSE_BOUND
     assert got_far.std() > 0.01   # the far camera still sees the scene
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_soups_on_the_device(rt, orc, renderer, seed):
+    """Random sphere/quad soups with instances (tests/test_fast_order_random.py): the kernels on the flat list agree with
+    the oracle, and rtk_scene_upload_fast renders the same bytes."""
+    from tests.test_fast_order_random import look_at_camera, random_scene
+
+    scene = random_scene(2000 + seed)
+    cam = look_at_camera(rt)
+    ref, ref8, ocnt = orc.render(scene.desc_ptr, cam, 7, 4)
+    renderer.upload(scene)
+    gpu, gpu8, cnt = renderer.render_host(cam, seed=7, count=True)
+    assert rmse(gpu, ref) < F64_RMSE_BOUND and np.array_equal(gpu8, ref8) and cnt == ocnt
+    info = renderer.upload_fast(scene, cam.center)
+    assert info["exact"]
+    fast, fast8, _ = renderer.render_host(cam, seed=7)
+    assert np.array_equal(fast, gpu) and np.array_equal(fast8, gpu8)

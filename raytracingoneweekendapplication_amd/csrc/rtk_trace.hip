@@ -1062,7 +1062,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
     if (lane == 0) prefetched_item = atomicAdd(tile_counter, 1u);
     bool exhausted = false;
     // tools/: A/B of the refill batch size through variant bits 14..16 (0 = default)
-    constexpr int kRefillMinTable[8] = {8, 1, 4, 8, 16, 24, 32, 12};
+    constexpr int kRefillMinTable[8] = {4, 1, 4, 8, 16, 24, 32, 12};
     const int refill_min = kRefillMinTable[(diag >> 14) & 7];
     constexpr int kSphereMinTable[8] = {16, 65, 4, 8, 12, 16, 24, 32};  // variant bits 17..19; 65 = never (spheres only through the vote)
     const int sphere_sel = int(diag >> 17) & 7;
@@ -1298,26 +1298,59 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             } while (remaining >= keep);
           }
         } else if (pick == W_SHADE) {
+            // 1. the body of ray_color for the lanes whose segment ended; a finished (pixel, chunk) is written out
+            bool finished = false, next_sample = false, alive = false;
             if (kind == OP_END) {
-                bool alive = true;
+                alive = true;
                 const bool ended = L.depth <= 0 || shade<real, FEAT, COUNT>(L, prog, sc, mats, cam, cnt);
                 if (ended) {  // pixel_color += ray_color(...) (Camera.txt:72)
                     L.sum = L.sum + L.radiance;
                     L.s += 1;
                     if (L.s < s_end) {
-                        begin_sample(L, cam, px_i, px_j, seed_hash, cnt);
+                        next_sample = true;
                     } else {
+                        finished = true;
                         alive = false;
                         L.kind = OP_DEAD;
                         store_partial(partial, my_slot, my_pix, L.sum);
                         if (tile_cost && cost_tile >= 0) atomicAdd(&tile_cost[cost_tile], L.segs);  // no return value: fire and forget
                     }
                 }
-                if (alive) {
-                    if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0, MIXED>(L, cnt, extent);
-                    else L.pc = end_pc;
-                    L.kind = prog[L.pc].kind_payload & 15u;
+            }
+            // 2. lanes that just finished take the next pixels of the wave's current work item right here, so that
+            // their begin_sample / begin_segment is the code the continuing lanes execute anyway; a separate refill
+            // round costs as much as a shade step and serves a dozen lanes.  Only what the current item still holds:
+            // fetching the next item stays with the batched refill at the top of the loop.
+            // (Not in the quad/box subset kernel, which is short of registers: A/B on C3 34.5 vs 35.4 ms; C2 24.4 -> 23.0.)
+            constexpr bool kRefillInShade = (FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX)) != kFeatQuadBox;
+            const unsigned long long m_fin = kRefillInShade ? __ballot(finished) : 0ull;
+            if (uniform(m_fin != 0ull && refill_next < 64)) {
+                const int avail = 64 - refill_next;
+                const int rank_in_fin = int(__builtin_amdgcn_mbcnt_hi(uint32_t(m_fin >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m_fin), 0u)));
+                if (finished && rank_in_fin < avail) {
+                    my_pix = refill_next + rank_in_fin;
+                    my_slot = it_slot;
+                    px_i = it_x0 + (my_pix & 7);
+                    px_j = it_y0 + (my_pix >> 3);
+                    s_end = it_s_end;
+                    if (it_ok && px_i < width && px_j < height) {
+                        L.sum = mk(real(0), real(0), real(0));
+                        L.s = it_s_begin;
+                        L.segs = 0;
+                        cost_tile = it_cost_tile;
+                        alive = true;
+                        next_sample = true;
+                    }
                 }
+                const int n_fin = popcount64(m_fin);
+                refill_next += n_fin < avail ? n_fin : avail;
+            }
+            // 3. the next sample of the same or of the new pixel, then the next segment
+            if (next_sample) begin_sample(L, cam, px_i, px_j, seed_hash, cnt);
+            if (alive) {
+                if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0, MIXED>(L, cnt, extent);
+                else L.pc = end_pc;
+                L.kind = prog[L.pc].kind_payload & 15u;
             }
             RTK_PROF_MARK(3, 1, n_shd)
         } else {

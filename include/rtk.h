@@ -200,7 +200,7 @@ typedef struct rtk_render_opts {
     int32_t variant;        /* 0 = default.  Bit flags for A/B measurements and tests; none of them changes what is
                              * computed: 1 = keep the traversal program in global memory (no LDS staging);
                              * 2 = one sample chunk per pixel; 4 = fixed row-major tile order (no cost-ordered
-                             * hand-out); bits 3-4 = chunk size (0: 4 samples, 1: 8, 2: 2, 3: 16);
+                             * hand-out); bits 3-4 = chunk size (0: 8 samples, 1: 4, 2: 2, 3: 16);
                              * bits 8-13 = scheduler loop-exit thresholds, bits 14-16 = refill batch size, bits 17-19 = lanes needed
                              * for a sphere step inside the box loop (see csrc/rtk_trace.hip) */
     void* stream;           /* hipStream_t, NULL = default stream */

@@ -711,16 +711,17 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
     tm.compact = opts->n_ranks > 1 ? 1 : 0;
     tm.order_in_lds = 0;
     tm.order_lds_offset = 0;
-    // Split every pixel's samples into chunks of 4 (at most 64 chunks) so that no lane is stuck with a whole
-    // heavy pixel: a glass pixel's samples cost ~0.5 ms each, and the largest (pixel, chunk) bounds the end of
-    // the frame whatever the GPU count.  Measured on C2 (kernel time, N = 1 / one of 8 shards): 8-sample chunks
-    // 70.0 / 11.5 ms, 4-sample 72.2 / 10.2 ms, 2-sample 74.0 / 10.3 ms.  A function of spp only.
+    // Split every pixel's samples into chunks of 8 (at most 64 chunks) so that no lane is stuck with a whole
+    // heavy pixel: a glass pixel's samples cost ~0.2 ms each, and the largest (pixel, chunk) bounds the end of
+    // the frame whatever the GPU count.  Measured on C2 (v16 kernel time, N = 1 / one of 8 shards): 4-sample chunks
+    // 22.8 / 3.21 ms, 8-sample 21.8 / 3.21 ms, 16-sample 21.7 / 3.60 ms (with the v9 kernel, whose refills were
+    // dearer, 4 was the optimum).  A function of spp only.
     {
         const int spp = cam->samples_per_pixel;
         int n = 0;
         tm.chunk_start[0] = 0;
-        const int ab = (opts->variant >> 3) & 3;  // tools/: chunk size A/B (0 = default 4, 1 = 8, 2 = 2, 3 = 16)
-        int size = ab == 0 ? 4 : (ab == 1 ? 8 : (ab == 2 ? 2 : 16));
+        const int ab = (opts->variant >> 3) & 3;  // tools/: chunk size A/B (0 = default 8, 1 = 4, 2 = 2, 3 = 16)
+        int size = ab == 0 ? 8 : (ab == 1 ? 4 : (ab == 2 ? 2 : 16));
         if (opts->variant & 2) size = spp;  // variant bit 1: one lane per pixel for all samples (tests)
         while ((spp + size - 1) / size > kMaxChunks) size++;
         for (int s0 = size; s0 < spp; s0 += size) tm.chunk_start[++n] = int16_t(s0);

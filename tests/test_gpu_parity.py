@@ -89,7 +89,7 @@ def test_f32_kernel_agrees_statistically(rt, orc, renderer, scenes, name):
 
 def test_sample_chunking_changes_only_the_summation_order(rt, orc, renderer, scenes):
     scene = scenes("book1_final")
-    cam = scene.camera(64, 40, 50, 50)          # 50 spp -> 12 chunks of 4 and one of 2
+    cam = scene.camera(64, 40, 50, 50)          # 50 spp -> 6 chunks of 8 and one of 2
     renderer.upload(scene)
     chunked, _, c1 = renderer.render_host(cam, count=True)
     single, _, c2 = renderer.render_host(cam, count=True, variant=2)   # one lane per pixel for all samples

@@ -1187,11 +1187,12 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             const int keep = frac > 8 ? frac : 8;
             // Box steps per trip around the loop's scalar checks.  Measured per kernel (tools/ab): the MIXED sphere kernel
             // (long runs of cheap box steps) 27.8 / 26.3 / 25.5 / 24.8 / 24.6 ms at 1 / 2 / 4 / 6 / 8; the reference-order
-            // kernels lose with any unrolling (C2 53.2 -> 54.8 at 4; C4 62.6 -> 64.2), the full-feature kernel gains 1 % at 2.
+            // kernels lose with any unrolling (C2 53.2 -> 54.8 at 4; C4 62.6 -> 64.2), the full-feature kernel gains 1 % at 2;
+            // the fused-slab sphere kernels (f32 mode, f64 fallback) behave like the MIXED one (f32: 20.6 -> 18.8 ms at 8).
 #ifndef RTK_UNROLL_MIXED
 #define RTK_UNROLL_MIXED 8
 #endif
-            constexpr int kBoxUnroll = MIXED ? RTK_UNROLL_MIXED : ((FEAT & ~uint32_t(F_FMA_BOX)) == kFeatAll ? 2 : 1);
+            constexpr int kBoxUnroll = (MIXED || FEAT == (kFeatLean | uint32_t(F_FMA_BOX))) ? RTK_UNROLL_MIXED : ((FEAT & ~uint32_t(F_FMA_BOX)) == kFeatAll ? 2 : 1);
             ProgRec cur = prog[L.pc];  // the record at L.pc (its first 32 bytes in the MIXED layout), held in registers: one LDS round trip per step
             uint32_t k = kind;
             const uint32_t box_kind = L.box_kind;  // a lane with an irregular ray matches nothing here: it never steps in this loop

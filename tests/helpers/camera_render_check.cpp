@@ -1,0 +1,72 @@
+// GPU test helper: the drop-in C++ path end to end -- scene through the reference-style API, camera::render_to in the
+// reference order, in the automatic order and in the forced fast order -- and a one-line JSON verdict on stdout.
+#include "rtweekend.h"
+
+#include "bvh.h"
+#include "camera.h"
+#include "constant_medium.h"
+#include "hittable_list.h"
+#include "material.h"
+#include "quad.h"
+#include "sphere.h"
+
+#include <cstring>
+
+static hittable_list spheres_scene(bool with_fog) {
+    hittable_list world;
+    world.add(make_shared<sphere>(point3(0, -1000, 0), 1000, make_shared<lambertian>(color(0.5, 0.5, 0.5))));
+    for (int a = -4; a < 4; a++)
+        for (int b = -4; b < 4; b++) {
+            point3 centre(a + 0.9 * random_double(), 0.2, b + 0.9 * random_double());
+            double pick = random_double();
+            shared_ptr<material> m;
+            if (pick < 0.6) m = make_shared<lambertian>(color(random_double(), random_double(), random_double()));
+            else if (pick < 0.85) m = make_shared<metal>(color(0.7, 0.6, 0.5), 0.3 * random_double());
+            else m = make_shared<dielectric>(1.5);
+            world.add(make_shared<sphere>(centre, 0.2, m));
+        }
+    world.add(make_shared<sphere>(point3(0, 1, 0), 1.0, make_shared<dielectric>(1.5)));
+    world.add(make_shared<quad>(point3(-2, 3, -2), vec3(4, 0, 0), vec3(0, 0, 4), make_shared<diffuse_light>(color(3, 3, 3))));
+    if (with_fog) world.add(make_shared<constant_medium>(make_shared<sphere>(point3(2, 0.7, 1), 0.7, make_shared<dielectric>(1.5)), 1.2, color(.9, .9, 1)));
+    return hittable_list(make_shared<bvh_node>(world));
+}
+
+int main() {
+    rtk::seed_scene_rng(1234);
+    std::vector<point_light> lights;
+    camera cam;
+    cam.image_width = 160;
+    cam.aspect_ratio = 16.0 / 9.0;
+    cam.samples_per_pixel = 8;
+    cam.max_depth = 12;
+    cam.background = color(0.7, 0.8, 1.0);
+    cam.vfov = 30;
+    cam.lookfrom = point3(9, 2.5, 4);
+    cam.lookat = point3(0, 0.5, 0);
+    cam.write_image = false;
+    bool ok = true;
+    std::printf("{");
+    for (int fog = 0; fog < 2; fog++) {
+        hittable_list world = spheres_scene(fog != 0);
+        std::vector<double> ref, aut, fast;
+        cam.order = camera::reference_order;
+        int rc0 = cam.render_to(world, lights, &ref, nullptr);
+        cam.order = camera::auto_order;
+        int rc1 = cam.render_to(world, lights, &aut, nullptr);
+        const bool auto_used_fast = cam.used_fast_order, exact = cam.fast_order_exact;
+        cam.order = camera::fast_order;
+        int rc2 = cam.render_to(world, lights, &fast, nullptr);
+        const bool same_auto = ref.size() == aut.size() && std::memcmp(ref.data(), aut.data(), ref.size() * sizeof(double)) == 0;
+        const bool same_fast = ref.size() == fast.size() && std::memcmp(ref.data(), fast.data(), ref.size() * sizeof(double)) == 0;
+        double mean_ref = 0, mean_fast = 0;
+        for (double v : ref) mean_ref += v;
+        for (double v : fast) mean_fast += v;
+        std::printf("%s\"fog%d\": {\"rc\": [%d, %d, %d], \"exact\": %s, \"auto_used_fast\": %s, \"auto_identical\": %s, \"fast_identical\": %s, "
+                    "\"mean_ref\": %.6f, \"mean_fast\": %.6f}",
+                    fog ? ", " : "", fog, rc0, rc1, rc2, exact ? "true" : "false", auto_used_fast ? "true" : "false", same_auto ? "true" : "false",
+                    same_fast ? "true" : "false", mean_ref / ref.size(), mean_fast / fast.size());
+        ok = ok && rc0 == 0 && rc1 == 0 && rc2 == 0;
+    }
+    std::printf("}\n");
+    return ok ? 0 : 1;
+}

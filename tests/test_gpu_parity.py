@@ -431,3 +431,28 @@ def test_random_soups_on_the_device(rt, orc, renderer, seed):
     assert info["exact"]
     fast, fast8, _ = renderer.render_host(cam, seed=7)
     assert np.array_equal(fast, gpu) and np.array_equal(fast8, gpu8)
+
+
+def test_cpp_camera_render_through_the_drop_in_api(rt, tmp_path):
+    """The C++ side of the boundary end to end (host/rtk_camera.h): a reference-style program builds its scene with the
+    drop-in classes and calls camera::render_to.  auto_order must pick the fast order exactly when it is bit-identical
+    (no constant_medium) and then give the very same doubles as reference_order; with a medium it must stay on the
+    reference order (identical again), while the forced fast order is only statistically the same image."""
+    import json
+    import subprocess
+
+    from tests.conftest import ROOT
+
+    pkg = os.path.join(ROOT, "raytracingoneweekendapplication_amd")
+    exe = str(tmp_path / "camera_render_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "helpers", "camera_render_check.cpp"),
+                           "-I" + os.path.join(pkg, "host"), "-I" + os.path.join(ROOT, "include"), "-L" + pkg, "-lrtk_hip",
+                           "-Wl,-rpath," + pkg, "-o", exe])
+    out = subprocess.check_output([exe], timeout=300).decode()
+    verdict = json.loads(out.strip().splitlines()[-1])
+    clear, fog = verdict["fog0"], verdict["fog1"]
+    assert clear["rc"] == [0, 0, 0] and fog["rc"] == [0, 0, 0]
+    assert clear["exact"] and clear["auto_used_fast"] and clear["auto_identical"] and clear["fast_identical"]
+    assert not fog["exact"] and not fog["auto_used_fast"] and fog["auto_identical"]
+    assert abs(fog["mean_fast"] - fog["mean_ref"]) < 0.03 * fog["mean_ref"]
+    assert clear["mean_ref"] > 0.05

@@ -276,6 +276,27 @@ def main():
                     "note": "achieved = algorithmic bytes (SURVEY 8(d) model x exact counters) / kernel time; the program is served from LDS, so frac can exceed 1 -- see DESIGN.md section 5",
                     "per_sample": {k: round(counters[k] / counters["samples"], 4) for k in rt.COUNTER_FIELDS if k != "samples"}}
 
+    # ---- the achievable HBM bandwidth of THIS device beside the spec peak: a 1 GiB device-to-device copy
+    if rank == 0 and roofline is not None:
+        try:
+            src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+            dst = torch.empty_like(src)
+            best = None
+            for _ in range(4):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dst.copy_(src)
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1)
+                best = ms if best is None else min(best, ms)
+            measured = 2 * src.numel() * 4 / (best * 1e-3) / 1e9
+            roofline["peak_measured"] = round(measured, 1)
+            roofline["frac_of_measured_peak"] = round(roofline["achieved"] / measured, 4)
+            del src, dst
+        except Exception:  # reported, never required
+            roofline["peak_measured"] = None
+
     f32_mode = None
     if not args.no_f32:
         e32, k32, _ = timed(rt.RTK_REAL_F32, max(1, min(args.steps, 3)), 1)

@@ -29,6 +29,7 @@
 #include "glm_min.h"  // glm::vec2 for triangle UVs (triangle.h:137-139); the full GLM is not a dependency
 #include "rtk.h"
 #include "rtk_jpeg.h"
+#include "rtk_png.h"
 #include "rtk_math.h"
 
 namespace rtk {
@@ -115,8 +116,8 @@ public:
 // ===========================================================================
 // Image data behind image_texture (reference: rtw_stb_image.h).  This loader
 // reads baseline JPEG (rtk_jpeg.h: the reference's earthmap.jpg / male_texture.jpg,
-// decoded to the very bytes stb_image yields -- SURVEY 8(f) row 4), binary PPM
-// (P6) and raw RGB8 buffers.  The reference pipeline is
+// decoded to the very bytes stb_image yields -- SURVEY 8(f) row 4), PNG (rtk_png.h),
+// binary PPM (P6) and raw RGB8 buffers.  The reference pipeline is
 // stbi_loadf -> float -> float_to_byte (rtw_stb_image.h:53-66,99-121), i.e. the
 // texels the sample loop sees are int(256 * (b/255)^2.2); from_file applies the
 // same mapping so that a PPM gives the bytes the reference would hold.
@@ -153,6 +154,9 @@ public:
         if (file.size() > 3 && file[0] == 0xFF && file[1] == 0xD8) {
             rtk::jpeg_decoder jpeg;  // baseline JPEG, decoded to the bytes stb_image produces (rtk_jpeg.h)
             if (!jpeg.decode(file.data(), file.size(), iw, ih, raw)) return false;
+        } else if (file.size() > 8 && file[0] == 0x89 && file[1] == 'P' && file[2] == 'N' && file[3] == 'G') {
+            rtk::png_decoder png;  // every PNG colour type / depth / interlace, reduced to RGB8 the way stbi_load(..., 3) does (rtk_png.h)
+            if (!png.decode(file.data(), file.size(), iw, ih, raw)) return false;
         } else if (!parse_ppm(file, iw, ih, raw)) {
             return false;
         }

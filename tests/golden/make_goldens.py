@@ -97,7 +97,117 @@ def make_jpeg_fixtures():
         print(name, os.path.getsize(path), "bytes")
 
 
+
+
+def make_png_fixtures():
+    """Small PNGs of every colour type / bit depth / interlace combination, hand-assembled (zlib + scanline filters of
+    all five types) so that nothing depends on an imaging library's defaults, + the bytes the REFERENCE's rtw_image
+    holds for them (ref_driver texels)."""
+    import struct
+    import zlib
+
+    rng = np.random.default_rng(777)
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
+
+    def filter_row(ftype, row, prev, bpp):
+        out = bytearray(len(row))
+        for i in range(len(row)):
+            a = row[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            if ftype == 0: p = 0
+            elif ftype == 1: p = a
+            elif ftype == 2: p = b
+            elif ftype == 3: p = (a + b) >> 1
+            else:
+                pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            out[i] = (row[i] - p) & 0xFF
+        return bytes(out)
+
+    def pack_rows(samples, w, h, channels, depth):
+        """samples[h][w][channels] ints < 2^depth -> list of packed scanlines."""
+        rows = []
+        for j in range(h):
+            if depth == 8:
+                rows.append(bytes(int(v) for px in samples[j] for v in px))
+            elif depth == 16:
+                rows.append(b"".join(struct.pack(">H", int(v)) for px in samples[j] for v in px))
+            else:
+                bits = "".join(format(int(v), "0%db" % depth) for px in samples[j] for v in px)
+                bits += "0" * (-len(bits) % 8)
+                rows.append(bytes(int(bits[k:k + 8], 2) for k in range(0, len(bits), 8)))
+        return rows
+
+    def encode(name, w, h, colour, depth, interlace, palette=None, trns=None, split_idat=False, level=6):
+        channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[colour]
+        samples = rng.integers(0, 1 << depth, (h, w, channels))
+        if colour == 3:
+            samples = rng.integers(0, len(palette) // 3, (h, w, 1))
+        bpp = max(1, channels * depth // 8)
+        raw = bytearray()
+        passes = [(0, 0, 1, 1)] if not interlace else [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]
+        f = 0
+        for (x0, y0, dx, dy) in passes:
+            sub = samples[y0::dy, x0::dx]
+            if sub.shape[0] == 0 or sub.shape[1] == 0:
+                continue
+            rows = pack_rows(sub, sub.shape[1], sub.shape[0], channels, depth)
+            prev = bytes(len(rows[0]))
+            for row in rows:
+                ftype = f % 5
+                f += 1
+                raw.append(ftype)
+                raw += filter_row(ftype, row, prev, bpp)
+                prev = row
+        z = zlib.compress(bytes(raw), level)
+        body = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, colour, 0, 0, interlace))
+        body += chunk(b"gAMA", struct.pack(">I", 45455))
+        if palette is not None:
+            body += chunk(b"PLTE", bytes(palette))
+        if trns is not None:
+            body += chunk(b"tRNS", bytes(trns))
+        if split_idat:
+            third = max(1, len(z) // 3)
+            for k in range(0, len(z), third):
+                body += chunk(b"IDAT", z[k:k + third])
+        else:
+            body += chunk(b"IDAT", z)
+        body += chunk(b"tEXt", b"Comment\x00synthetic fixture") + chunk(b"IEND", b"")
+        path = os.path.join(HERE, name + ".png")
+        open(path, "wb").write(body)
+        prefix = os.path.join(tempfile.mkdtemp(), name)
+        subprocess.check_call([REF, "texels", path, prefix])
+        dims = np.fromfile(prefix + ".dims", np.int32)
+        assert dims.tolist() == [w, h], (name, dims)
+        np.save(os.path.join(HERE, name + "_texels.npy"), np.fromfile(prefix + ".u8", np.uint8).reshape(h, w, 3))
+        print(name, len(body), "bytes")
+
+    pal = [int(v) for v in rng.integers(0, 256, 16 * 3)]
+    encode("png_rgb8_13x7", 13, 7, 2, 8, 0)
+    encode("png_rgba8_9x9_adam7", 9, 9, 6, 8, 1, split_idat=True)
+    encode("png_grey8_17x5", 17, 5, 0, 8, 0)
+    encode("png_grey4_11x6", 11, 6, 0, 4, 0)
+    encode("png_grey2_10x4_adam7", 10, 4, 0, 2, 1)
+    encode("png_grey1_19x3", 19, 3, 0, 1, 0, trns=[0, 1])
+    encode("png_greyalpha8_8x8", 8, 8, 4, 8, 0)
+    encode("png_grey16_6x5", 6, 5, 0, 16, 0)
+    encode("png_rgb16_7x4_adam7", 7, 4, 2, 16, 1)
+    encode("png_rgba16_5x5", 5, 5, 6, 16, 0)
+    encode("png_pal8_12x5", 12, 5, 3, 8, 0, palette=pal, trns=[0, 128, 255])
+    encode("png_pal4_9x7_adam7", 9, 7, 3, 4, 1, palette=pal)
+    encode("png_pal2_15x2", 15, 2, 3, 2, 0, palette=pal[:12])
+    encode("png_pal1_21x3", 21, 3, 3, 1, 0, palette=pal[:6])
+    encode("png_rgb8_1x1_stored", 1, 1, 2, 8, 0, level=0)
+    encode("png_rgb8_64x48_fixedhuff", 64, 48, 2, 8, 0, level=1)
+
+
 if __name__ == "__main__":
-    if "--jpeg-only" not in sys.argv:
+    if "--jpeg-only" not in sys.argv and "--png-only" not in sys.argv:
         main()
-    make_jpeg_fixtures()
+    if "--png-only" not in sys.argv:
+        make_jpeg_fixtures()
+    if "--jpeg-only" not in sys.argv:
+        make_png_fixtures()

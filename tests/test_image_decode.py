@@ -1,4 +1,4 @@
-"""CPU tests of image-texture loading (rtw_stb_image.h:23-121).
+"""CPU tests of image-texture loading (rtw_stb_image.h:23-121): baseline JPEG, PNG, PPM.
 
 The texels are inputs of the sample loop, so the loader must hand the kernels the very bytes the reference's
 rtw_image holds: stb_image's JPEG decode (its integer inverse DCT, its chroma filter, its fixed-point colour
@@ -24,6 +24,35 @@ def test_jpeg_texels_equal_the_reference_loaders_bytes(rt, name):
     want = np.load(os.path.join(GOLDEN, name + "_texels.npy"), allow_pickle=False)
     assert got is not None and got.shape == want.shape
     assert np.array_equal(got, want)
+
+
+PNG_FIXTURES = ["png_rgb8_13x7", "png_rgba8_9x9_adam7", "png_grey8_17x5", "png_grey4_11x6", "png_grey2_10x4_adam7", "png_grey1_19x3",
+                "png_greyalpha8_8x8", "png_grey16_6x5", "png_rgb16_7x4_adam7", "png_rgba16_5x5", "png_pal8_12x5", "png_pal4_9x7_adam7",
+                "png_pal2_15x2", "png_pal1_21x3", "png_rgb8_1x1_stored", "png_rgb8_64x48_fixedhuff"]
+
+
+@pytest.mark.parametrize("name", PNG_FIXTURES)
+def test_png_texels_equal_the_reference_loaders_bytes(rt, name):
+    """Every PNG colour type (grey, RGB, palette, grey+alpha, RGBA), bit depth (1, 2, 4, 8, 16) and both interlace
+    methods, all five scanline filters, stored / fixed / dynamic deflate blocks, split IDAT, ancillary chunks."""
+    got = rt.load_image_texels(os.path.join(GOLDEN, name + ".png"))
+    want = np.load(os.path.join(GOLDEN, name + "_texels.npy"), allow_pickle=False)
+    assert got is not None and got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+def test_damaged_png_files_fail_to_load(rt):
+    data = open(os.path.join(GOLDEN, "png_rgb8_13x7.png"), "rb").read()
+    with tempfile.TemporaryDirectory() as tmp:
+        for cut in (7, 20, 60, len(data) - 30):
+            p = os.path.join(tmp, f"cut{cut}.png")
+            open(p, "wb").write(data[:cut])
+            assert rt.load_image_texels(p) is None
+        bad = bytearray(data)
+        bad[25] = 7   # an invalid colour type in IHDR
+        p = os.path.join(tmp, "badtype.png")
+        open(p, "wb").write(bytes(bad))
+        assert rt.load_image_texels(p) is None
 
 
 def test_ppm_goes_through_the_same_byte_mapping(rt):
@@ -52,7 +81,8 @@ def test_unsupported_and_damaged_files_fail_to_load(rt):
 
 
 def test_reference_textures_decode_identically_where_the_reference_exists(rt, orc):
-    files = ["/root/reference/Images/earthmap.jpg", "/root/reference/male_texture.jpg"]
+    files = ["/root/reference/Images/earthmap.jpg", "/root/reference/male_texture.jpg", "/root/reference/Images/Sky.png",
+             "/root/reference/Images/ImageOutputColors.png", "/root/reference/Images/final.png"]
     if not (os.path.exists(orc.REF_DRIVER) and all(os.path.exists(f) for f in files)):
         pytest.skip("needs /root/reference and oracle/_ref (build container only)")
     for f in files:

@@ -1,4 +1,4 @@
-// rtk_jpeg.h -- baseline JPEG decoding for image_texture.
+// rtk_jpeg.h -- JPEG decoding (sequential and progressive) for image_texture.
 //
 // The reference loads textures through rtw_image (rtw_stb_image.h:23-66), i.e.
 // stbi_loadf of the vendored stb_image.h: earthmap.jpg (main.cpp:152,311;
@@ -27,10 +27,11 @@
 // reference's own loader (oracle/_ref) on generated fixtures and, where
 // /root/reference exists, on earthmap.jpg and male_texture.jpg themselves.
 //
-// Supported: SOF0 (baseline sequential) and SOF1 with 8-bit precision, 1 or 3
+// Supported: SOF0 / SOF1 (sequential) and SOF2 (progressive: spectral selection
+// and successive approximation, T.81 G.1.2) with 8-bit precision, 1 or 3
 // components, any sampling factors up to 4, restart intervals, 16-bit DQT
 // entries.  Not supported (load fails, width() == 0 as rtw_stb_image.h:62 has it on
-// a failed load): progressive (SOF2), arithmetic coding, 12-bit samples, CMYK.
+// a failed load): arithmetic coding, lossless / hierarchical, 12-bit samples, CMYK.
 #ifndef RTK_JPEG_H
 #define RTK_JPEG_H
 
@@ -61,11 +62,14 @@ public:
                 if (!decode_scan()) return false;
                 break;  // baseline, interleaved: one scan carries the image (non-interleaved files loop below)
             }
-            if (m == 0xC0 || m == 0xC1) {
+            if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
                 if (have_frame || !read_frame_header()) return false;
                 have_frame = true;
-            } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-                return false;  // progressive / lossless / arithmetic
+                progressive = m == 0xC2;
+                if (progressive)
+                    for (int c = 0; c < n_comp; c++) comp[c].coef.assign(size_t(comp[c].blocks_w) * comp[c].blocks_h * 64, 0);
+            } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+                return false;  // lossless / hierarchical / arithmetic coding
             } else if (m == 0xC4) {
                 if (!read_huffman_tables()) return false;
             } else if (m == 0xDB) {
@@ -96,6 +100,7 @@ public:
                 break;
             }
         }
+        if (progressive) finish_progressive();
         width = img_w;
         height = img_h;
         to_rgb(rgb);
@@ -115,6 +120,7 @@ private:
         int plane_w, plane_h;
         int dc_pred;
         std::vector<uint8_t> plane;
+        std::vector<int16_t> coef;  // progressive only: the coefficients of every block, accumulated over the scans
     };
 
     const uint8_t* src = nullptr;
@@ -124,6 +130,8 @@ private:
     uint16_t quant[4][64];
     huffman dc_tab[4], ac_tab[4];
     int scan_n = 0, scan_comp[4];
+    bool progressive = false;
+    int spec_start = 0, spec_end = 63, succ_high = 0, succ_low = 0, eob_run = 0;
     // bit reader
     uint32_t bit_buf = 0;
     int bit_cnt = 0;
@@ -248,7 +256,17 @@ private:
             scan_comp[k] = which;
         }
         const uint8_t* q = p + 1 + 2 * scan_n;
-        if (q[0] != 0 || q[1] != 63 || q[2] != 0) return false;  // spectral selection / approximation of a sequential scan
+        spec_start = q[0];
+        spec_end = q[1];
+        succ_high = q[2] >> 4;
+        succ_low = q[2] & 15;
+        if (progressive) {
+            if (spec_start > 63 || spec_end > 63 || spec_start > spec_end || succ_high > 13 || succ_low > 13) return false;
+            if (spec_start == 0 && spec_end != 0) return false;   // a DC scan carries the DC coefficient only
+            if (spec_start != 0 && scan_n != 1) return false;     // AC scans are not interleaved
+        } else if (spec_start != 0 || spec_end != 63 || q[2] != 0) {
+            return false;  // spectral selection / approximation in a sequential scan
+        }
         src += len;
         return true;
     }
@@ -396,7 +414,153 @@ private:
         }
     }
 
+    // ---- progressive (SOF2) scans, T.81 G.1.2: coefficients accumulate in comp.coef and are transformed at the end
+    bool decode_block_prog_dc(component& c, int16_t* data) {
+        if (succ_high == 0) {
+            const huffman& dc = dc_tab[c.td];
+            if (!dc.present) return false;
+            int s = decode_symbol(dc);
+            if (s < 0 || s > 15) return false;
+            int diff = s ? extend(get_bits(s), s) : 0;
+            c.dc_pred += diff;
+            data[0] = int16_t(c.dc_pred * (1 << succ_low));
+        } else if (get_bits(1)) {
+            data[0] = int16_t(data[0] + (1 << succ_low));
+        }
+        return true;
+    }
+    bool decode_block_prog_ac(component& c, int16_t* data) {
+        const huffman& ac = ac_tab[c.ta];
+        if (!ac.present) return false;
+        if (succ_high == 0) {  // first pass of this band
+            if (eob_run) {
+                --eob_run;
+                return true;
+            }
+            int k = spec_start;
+            do {
+                int rs = decode_symbol(ac);
+                if (rs < 0) return false;
+                int s = rs & 15, r = rs >> 4;
+                if (s == 0) {
+                    if (r < 15) {
+                        eob_run = (1 << r);
+                        if (r) eob_run += get_bits(r);
+                        --eob_run;
+                        break;
+                    }
+                    k += 16;
+                } else {
+                    k += r;
+                    if (k > 63) return false;
+                    data[zigzag()[k++]] = int16_t(extend(get_bits(s), s) * (1 << succ_low));
+                }
+            } while (k <= spec_end);
+            return true;
+        }
+        // refinement pass: one more bit for the coefficients already non-zero, new +-1 coefficients in between
+        const int16_t bit = int16_t(1 << succ_low);
+        auto refine = [&](int16_t* p) {
+            if (get_bits(1) && (*p & bit) == 0) *p = int16_t(*p > 0 ? *p + bit : *p - bit);
+        };
+        if (eob_run) {
+            --eob_run;
+            for (int k = spec_start; k <= spec_end; k++) {
+                int16_t* p = &data[zigzag()[k]];
+                if (*p != 0) refine(p);
+            }
+            return true;
+        }
+        int k = spec_start;
+        do {
+            int rs = decode_symbol(ac);
+            if (rs < 0) return false;
+            int s = rs & 15, r = rs >> 4;
+            if (s == 0) {
+                if (r < 15) {
+                    eob_run = (1 << r) - 1;
+                    if (r) eob_run += get_bits(r);
+                    r = 64;  // run to the end of the band
+                }           // else: sixteen zero coefficients to skip
+            } else {
+                if (s != 1) return false;
+                s = get_bits(1) ? bit : -bit;
+            }
+            while (k <= spec_end) {
+                int16_t* p = &data[zigzag()[k++]];
+                if (*p != 0) {
+                    refine(p);
+                } else {
+                    if (r == 0) {
+                        *p = int16_t(s);
+                        break;
+                    }
+                    --r;
+                }
+            }
+        } while (k <= spec_end);
+        return true;
+    }
+    bool decode_scan_progressive() {
+        reset_bits();
+        eob_run = 0;
+        for (int c = 0; c < n_comp; c++) comp[c].dc_pred = 0;
+        int todo = restart_interval ? restart_interval : 0x7fffffff;
+        auto after_unit = [&]() {
+            if (--todo > 0) return;
+            reset_bits_to_marker();
+            if (src + 1 < end && src[0] == 0xFF && src[1] >= 0xD0 && src[1] <= 0xD7) {
+                src += 2;
+                reset_bits();
+                eob_run = 0;
+                for (int c = 0; c < n_comp; c++) comp[c].dc_pred = 0;
+                todo = restart_interval ? restart_interval : 0x7fffffff;
+            }
+        };
+        if (scan_n == 1) {
+            component& c = comp[scan_comp[0]];
+            const int w = (((img_w * c.h + h_max - 1) / h_max) + 7) >> 3, h = (((img_h * c.v + v_max - 1) / v_max) + 7) >> 3;
+            for (int by = 0; by < h; by++)
+                for (int bx = 0; bx < w; bx++) {
+                    int16_t* data = c.coef.data() + (size_t(by) * c.blocks_w + bx) * 64;
+                    if (!(spec_start == 0 ? decode_block_prog_dc(c, data) : decode_block_prog_ac(c, data))) return false;
+                    after_unit();
+                }
+        } else {  // interleaved: DC only
+            const int mcus_x = comp[0].blocks_w / comp[0].h, mcus_y = comp[0].blocks_h / comp[0].v;
+            for (int my = 0; my < mcus_y; my++)
+                for (int mx = 0; mx < mcus_x; mx++) {
+                    for (int k = 0; k < scan_n; k++) {
+                        component& c = comp[scan_comp[k]];
+                        for (int v = 0; v < c.v; v++)
+                            for (int h = 0; h < c.h; h++) {
+                                int16_t* data = c.coef.data() + (size_t(my * c.v + v) * c.blocks_w + (mx * c.h + h)) * 64;
+                                if (!decode_block_prog_dc(c, data)) return false;
+                            }
+                    }
+                    after_unit();
+                }
+        }
+        reset_bits_to_marker();
+        return true;
+    }
+    // After the last scan: dequantise (16-bit wrap, as in the sequential path) and transform every block.
+    void finish_progressive() {
+        for (int ci = 0; ci < n_comp; ci++) {
+            component& c = comp[ci];
+            const int w = (((img_w * c.h + h_max - 1) / h_max) + 7) >> 3, h = (((img_h * c.v + v_max - 1) / v_max) + 7) >> 3;
+            const uint16_t* q = quant[c.tq];
+            for (int by = 0; by < h; by++)
+                for (int bx = 0; bx < w; bx++) {
+                    int16_t* data = c.coef.data() + (size_t(by) * c.blocks_w + bx) * 64;
+                    for (int k = 0; k < 64; k++) data[k] = int16_t(data[k] * q[k]);
+                    idct_block(data, c.plane.data() + size_t(by) * 8 * c.plane_w + bx * 8, c.plane_w);
+                }
+        }
+    }
+
     bool decode_scan() {
+        if (progressive) return decode_scan_progressive();
         reset_bits();
         for (int c = 0; c < n_comp; c++) comp[c].dc_pred = 0;
         int16_t coef[64];

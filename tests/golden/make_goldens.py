@@ -64,8 +64,8 @@ def main():
 
 
 def make_jpeg_fixtures():
-    """Small baseline JPEGs written by Pillow (synthetic content) + the bytes the REFERENCE's rtw_image holds for
-    them (ref_driver texels): 4:4:4, 4:2:0, 4:2:2, grey, sizes that are not multiples of the MCU, restart markers."""
+    """Small baseline and progressive JPEGs written by Pillow (synthetic content) + the bytes the REFERENCE's rtw_image
+    holds for them (ref_driver texels): 4:4:4, 4:2:0, 4:2:2, grey, sizes that are not multiples of the MCU, restart markers."""
     from PIL import Image
 
     rng = np.random.default_rng(20250418)
@@ -77,6 +77,11 @@ def make_jpeg_fixtures():
         "jpg_422_33x16": dict(size=(33, 16), subsampling=1, quality=95),
         "jpg_grey_19x21": dict(size=(19, 21), grey=True, quality=80),
         "jpg_420_64x64_noise": dict(size=(64, 64), subsampling=2, quality=60, noise=True),
+        "jpg_prog_444_40x24": dict(size=(40, 24), subsampling=0, quality=90, progressive=True),
+        "jpg_prog_420_37x23": dict(size=(37, 23), subsampling=2, quality=85, progressive=True),
+        "jpg_prog_422_33x16": dict(size=(33, 16), subsampling=1, quality=95, progressive=True),
+        "jpg_prog_grey_19x21": dict(size=(19, 21), grey=True, quality=80, progressive=True),
+        "jpg_prog_420_100x75_noise": dict(size=(100, 75), subsampling=2, quality=30, noise=True, progressive=True),
     }
     for name, c in cases.items():
         w, h = c["size"]
@@ -88,7 +93,7 @@ def make_jpeg_fixtures():
         path = os.path.join(HERE, name + ".jpg")
         kw = {k: v for k, v in c.items() if k in ("quality", "subsampling", "restart_marker_blocks")}
         im = Image.fromarray(img[:, :, 0] if c.get("grey") else img, "L" if c.get("grey") else "RGB")
-        im.save(path, "JPEG", optimize=False, progressive=False, **kw)
+        im.save(path, "JPEG", optimize=False, progressive=bool(c.get("progressive")), **kw)
         prefix = os.path.join(tempfile.mkdtemp(), name)
         subprocess.check_call([REF, "texels", path, prefix])
         dims = np.fromfile(prefix + ".dims", np.int32)

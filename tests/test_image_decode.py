@@ -15,7 +15,8 @@ import pytest
 
 from tests.conftest import GOLDEN
 
-FIXTURES = ["jpg_444_40x24", "jpg_420_37x23", "jpg_420_1x1", "jpg_420_17x9_rst", "jpg_422_33x16", "jpg_grey_19x21", "jpg_420_64x64_noise"]
+FIXTURES = ["jpg_444_40x24", "jpg_420_37x23", "jpg_420_1x1", "jpg_420_17x9_rst", "jpg_422_33x16", "jpg_grey_19x21", "jpg_420_64x64_noise",
+            "jpg_prog_444_40x24", "jpg_prog_420_37x23", "jpg_prog_422_33x16", "jpg_prog_grey_19x21", "jpg_prog_420_100x75_noise"]
 
 
 @pytest.mark.parametrize("name", FIXTURES)
@@ -66,8 +67,7 @@ def test_ppm_goes_through_the_same_byte_mapping(rt):
     assert (got == want).mean() > 0.99
 
 
-def test_unsupported_and_damaged_files_fail_to_load(rt):
-    assert rt.load_image_texels(os.path.join(GOLDEN, "jpg_progressive_16x16.jpg")) is None   # SOF2: not decoded here
+def test_missing_and_damaged_jpeg_files_fail_to_load(rt):
     assert rt.load_image_texels("/nonexistent/file.jpg") is None
     data = open(os.path.join(GOLDEN, "jpg_420_37x23.jpg"), "rb").read()
     with tempfile.TemporaryDirectory() as tmp:

@@ -113,6 +113,7 @@ struct Optimizer {
     bool failed = false;
     bool has_media = false;
     double margin = 0.0, tri_margin = 0.0;
+    int split_depth = 0;
     bool has_triangles = false;
     int64_t n_bvh_in = 0;
 
@@ -420,14 +421,19 @@ struct Optimizer {
                 }
             }
         }
+        // Degenerate inputs (thousands of coincident boxes) can make the heuristic peel off one item per level; past a
+        // depth no sane hierarchy needs, split at the median instead so that recursion depth and work stay bounded.
+        if (split_depth > 48 && (best_k == 1 || best_k + 1 == n)) best_k = n / 2;
         if (best_axis != 2)
             std::sort(items.begin() + long(begin), items.begin() + long(end), [&](const Item& x, const Item& y) {
                 const double cx = x.box.centre(best_axis), cy = y.box.centre(best_axis);
                 return cx != cy ? cx < cy : x.node < y.node;
             });
         const size_t mid = begin + best_k;
+        split_depth++;
         Built l = represent(items, begin, mid, b);
         Built r = represent(items, mid, end, b);
+        split_depth--;
         // visiting order of the two children (bvh.h:68-69 visits `left` first): nearer to the eye first; without
         // an eye, the side that is more likely to be hit
         bool swap = false;

@@ -69,3 +69,22 @@ def test_random_soups_render_identically_in_the_fast_order(rt, orc, seed):
             assert gc[k] == rc[k], k
         assert gc["box_tests"] > 0 and gc["sphere_tests"] + gc["quad_tests"] < rc["sphere_tests"] + rc["quad_tests"]
     assert ref.std() > 0.01   # the camera actually sees the soup
+
+
+def test_degenerate_scene_of_coincident_spheres_is_handled(rt, orc):
+    """Two thousand spheres on top of each other (identical boxes): the optimiser must neither recurse without bound nor
+    change the image -- the first sphere in list order wins every tie in the reference (strict `surrounds`), and with
+    identical materials any winner gives the same pixels."""
+    from tests.desc_builder import DescBuilder
+
+    b = DescBuilder()
+    m = b.lambertian((0.6, 0.4, 0.3))
+    members = [b.sphere((0.0, 0.0, -3.0), 0.8, m) for _ in range(2000)]
+    members.append(b.sphere((0, -101, -3), 100.0, b.lambertian((0.5, 0.5, 0.5))))
+    scene = b.finish(b.list(members))
+    cam = look_at_camera(rt)
+    fast = rt.FastOrderScene(scene, cam.center)
+    ref, _, _ = orc.render(scene.desc_ptr, cam, 7, 4)
+    got, _, cnt = orc.render(fast.desc_ptr, cam, 7, 4)
+    assert np.array_equal(got, ref)
+    assert cnt["sphere_tests"] > 0

@@ -672,6 +672,10 @@ static int upload_scene(rtk_ctx* ctx, const rtk_scene_desc* scene, uint32_t hier
         if (textured && scene->textures[m.texture].kind != RTK_TEX_SOLID) prog.features |= F_TEXTURE;
     }
     if (scene->n_lights > 0) prog.features |= F_LIGHTS;
+    bool matte = true;  // only lambertians and lights: the quad/box subset kernel drops its glossy branches (F_MATTE)
+    for (int32_t i = 0; i < scene->n_materials; i++)
+        if (scene->materials[i].kind != RTK_MAT_LAMBERTIAN && scene->materials[i].kind != RTK_MAT_DIFFUSE_LIGHT) matte = false;
+    if (matte) hierarchy_flags |= F_MATTE;
 
     RTK_HIP(hipSetDevice(ctx->device));
     ctx->has_scene = false;

@@ -103,7 +103,10 @@ enum Feature : uint32_t {
     F_FMA_BOX = 1u << 7,
     // f64 kernels only, sphere-only scenes: the MIXED program below -- conservative f32 culling boxes in 32-byte
     // records, exact f64 primitive tests (rtk_scene_upload_fast picks it when the scene qualifies).
-    F_F32_BOX = 1u << 8
+    F_F32_BOX = 1u << 8,
+    // A restriction, not a feature: every material is a lambertian or a light (the Cornell box).  The quad/box subset
+    // kernel then carries no metal / dielectric / isotropic / specular code at all.
+    F_MATTE = 1u << 9
 };
 constexpr uint32_t kFeatLean = 0;                       // spheres + lambertian/metal/dielectric with solid colours
 constexpr uint32_t kFeatAll = 0x7F;

@@ -850,7 +850,7 @@ RTK_DEV bool shade(Lane<real>& L, const ProgT* __restrict__ prog, const SceneVie
         if (near_zero(dir)) dir = sf.normal;
         next_d = dir;
         attenuation = material_color<real, FEAT>(sc, m, sf.u, sf.v, sf.p, cnt);
-    } else if (m.kind == RTK_MAT_METAL) {  // material.h:82-88
+    } else if (!(FEAT & F_MATTE) && m.kind == RTK_MAT_METAL) {  // material.h:82-88
         if constexpr (!kHoist) {
             ruv = random_unit_vector<real>(L.rng, cnt);
             unit_in = unit_vector(reflect(rd, sf.normal));
@@ -859,7 +859,7 @@ RTK_DEV bool shade(Lane<real>& L, const ProgT* __restrict__ prog, const SceneVie
         next_d = unit_in + fuzz;
         attenuation = ld3(m.albedo);
         scattered = dot(next_d, sf.normal) > real(0);
-    } else if (m.kind == RTK_MAT_DIELECTRIC) {  // material.h:47-65
+    } else if (!(FEAT & F_MATTE) && m.kind == RTK_MAT_DIELECTRIC) {  // material.h:47-65
         attenuation = mk(real(1), real(1), real(1));
         // 1/refraction_index and Schlick's r0^2 for both faces are per-material constants: computed once at upload,
         // in double, by the same expressions (material.h:50,71-72)
@@ -882,10 +882,10 @@ RTK_DEV bool shade(Lane<real>& L, const ProgT* __restrict__ prog, const SceneVie
             reflect_it = refl > rnd<real>(L.rng, cnt);
         }
         next_d = reflect_it ? reflect(unit_d, sf.normal) : refract(unit_d, sf.normal, ri);
-    } else if ((FEAT & F_EXOTIC_MAT) && m.kind == RTK_MAT_ISOTROPIC) {  // material.h:129-134
+    } else if ((FEAT & F_EXOTIC_MAT) && !(FEAT & F_MATTE) && m.kind == RTK_MAT_ISOTROPIC) {  // material.h:129-134
         next_d = random_unit_vector<real>(L.rng, cnt);
         attenuation = material_color<real, FEAT>(sc, m, sf.u, sf.v, sf.p, cnt);
-    } else if ((FEAT & F_EXOTIC_MAT) && m.kind == RTK_MAT_SPECULAR) {  // material.h:145-167
+    } else if ((FEAT & F_EXOTIC_MAT) && !(FEAT & F_MATTE) && m.kind == RTK_MAT_SPECULAR) {  // material.h:145-167
         if constexpr (!kHoist) unit_in = unit_vector(rd);
         const V3<real> unit_d = unit_in;
         const V3<real> refl = reflect(unit_d, sf.normal);
@@ -999,7 +999,7 @@ RTK_DEV void store_partial(real* __restrict__ partial, int item, int pix, V3<rea
 // the full-feature kernel, which needs far more registers (~560 B/lane of spills at 168), is fastest at 2 waves.
 template <typename real, uint32_t FEAT>
 constexpr int max_threads() {
-    constexpr uint32_t scene_feat = FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX);
+    constexpr uint32_t scene_feat = FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE);
     if (sizeof(real) == 8) return scene_feat == kFeatAll ? 512 : ((scene_feat == kFeatLean || scene_feat == kFeatQuadBox) ? 1024 : 768);
     return 768;
 }
@@ -1322,8 +1322,9 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             // their begin_sample / begin_segment is the code the continuing lanes execute anyway; a separate refill
             // round costs as much as a shade step and serves a dozen lanes.  Only what the current item still holds:
             // fetching the next item stays with the batched refill at the top of the loop.
-            // (Not in the quad/box subset kernel, which is short of registers: A/B on C3 34.5 vs 35.4 ms; C2 24.4 -> 23.0.)
-            constexpr bool kRefillInShade = (FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX)) != kFeatQuadBox;
+            // (Not in the glossy quad/box subset kernel, which is short of registers: A/B on C3 34.5 vs 35.4 ms; its matte
+            // variant has room: 32.3 -> 31.9.  C2 24.4 -> 23.0.)
+            constexpr bool kRefillInShade = (FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE)) != kFeatQuadBox || (FEAT & F_MATTE) != 0;
             const unsigned long long m_fin = kRefillInShade ? __ballot(finished) : 0ull;
             if (uniform(m_fin != 0ull && refill_next < 64)) {
                 const int avail = 64 - refill_next;
@@ -1629,10 +1630,10 @@ static bool use_mixed_program(const SceneView<real>& sc, uint32_t diag) {
 // Kernel instantiation for a scene: the leanest feature subset that covers it, with or without the fused slab test;
 // `mixed` = the scene has a MIXED program (f64, sphere-only, fast order) and the caller did not ask for the f64 boxes.
 static uint32_t kernel_features(uint32_t features, bool count, bool mixed) {
-    const uint32_t fma = features & F_FMA_BOX, scene = features & ~uint32_t(F_FMA_BOX);
+    const uint32_t fma = features & F_FMA_BOX, matte = features & F_MATTE, scene = features & ~uint32_t(F_FMA_BOX | F_MATTE);
     if (count) return kFeatAll | fma;
     if (scene == kFeatLean) return mixed ? (kFeatLean | uint32_t(F_F32_BOX)) : (kFeatLean | fma);
-    if ((scene & ~kFeatQuadBox) == 0) return kFeatQuadBox;  // no registers to spare for o*inv at 4 waves/SIMD (it spills): exact slab test, A/B on C3 40.7 vs 42.2 ms
+    if ((scene & ~kFeatQuadBox) == 0) return kFeatQuadBox | matte;  // no registers to spare for o*inv at 4 waves/SIMD (it spills): exact slab test, A/B on C3 40.7 vs 42.2 ms
     if ((scene & ~kFeatMesh) == 0) return kFeatMesh | fma;
     return kFeatAll | fma;
 }
@@ -1660,6 +1661,7 @@ hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>* cam, 
     switch (feat) {
         RTK_LAUNCH_CASE(kFeatLean)
         RTK_LAUNCH_CASE(kFeatQuadBox)
+        RTK_LAUNCH_CASE(kFeatQuadBox | F_MATTE)
         RTK_LAUNCH_CASE(kFeatMesh)
         RTK_LAUNCH_CASE(kFeatAll)
         RTK_LAUNCH_CASE(kFeatLean | F_FMA_BOX)

@@ -1634,7 +1634,7 @@ static uint32_t kernel_features(uint32_t features, bool count, bool mixed) {
     if (count) return kFeatAll | fma;
     if (scene == kFeatLean) return mixed ? (kFeatLean | uint32_t(F_F32_BOX)) : (kFeatLean | fma);
     if ((scene & ~kFeatQuadBox) == 0) return kFeatQuadBox | matte;  // no registers to spare for o*inv at 4 waves/SIMD (it spills): exact slab test, A/B on C3 40.7 vs 42.2 ms
-    if ((scene & ~kFeatMesh) == 0) return kFeatMesh | fma;
+    if ((scene & ~kFeatMesh) == 0) return kFeatMesh | fma | matte;
     return kFeatAll | fma;
 }
 
@@ -1666,6 +1666,8 @@ hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>* cam, 
         RTK_LAUNCH_CASE(kFeatAll)
         RTK_LAUNCH_CASE(kFeatLean | F_FMA_BOX)
         RTK_LAUNCH_CASE(kFeatMesh | F_FMA_BOX)
+        RTK_LAUNCH_CASE(kFeatMesh | F_MATTE)
+        RTK_LAUNCH_CASE(kFeatMesh | F_FMA_BOX | F_MATTE)
         RTK_LAUNCH_CASE(kFeatAll | F_FMA_BOX)
         case kFeatLean | F_F32_BOX:
             if constexpr (sizeof(real) == 8)

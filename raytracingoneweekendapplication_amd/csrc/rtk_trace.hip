@@ -961,7 +961,25 @@ RTK_DEV int popcount64(unsigned long long m) {
 // step count and active-lane count to counters[3*phase .. 3*phase+2].  The product build has none of it.
 #ifdef RTK_PROFILE
 #define RTK_PROF_DECL unsigned long long prof_t[6] = {0, 0, 0, 0, 0, 0}, prof_n[6] = {0, 0, 0, 0, 0, 0}, prof_l[6] = {0, 0, 0, 0, 0, 0}; \
-    unsigned long long prof_prev = __builtin_amdgcn_s_memtime();
+    unsigned long long prof_prev = __builtin_amdgcn_s_memtime();                                                                       \
+    const unsigned long long prof_wall0 = wall_clock64();                                                                              \
+    unsigned long long prof_wall_empty = 0, prof_chunk_t0 = 0;
+#define RTK_PROF_CHUNK_BEGIN prof_chunk_t0 = wall_clock64();
+#define RTK_PROF_CHUNK_END /* (pixel, chunk)s that ended after the work queue ran dry and took over 300 us: [31] count, then {begin, duration, segments, slot << 8 | pixel} from [32] on */ \
+    {                                                                                                                                  \
+        const unsigned long long dur_ = wall_clock64() - prof_chunk_t0;                                                                \
+        if (prof_wall_empty != 0 && dur_ > 30000ull) {                                                                                                       \
+            const unsigned long long i_ = atomicAdd(&counters[31], 1ull);                                                              \
+            if (i_ < 4096ull) {                                                                                                        \
+                counters[32 + 4 * i_] = prof_chunk_t0;                                                                                 \
+                counters[33 + 4 * i_] = dur_;                                                                                          \
+                counters[34 + 4 * i_] = (unsigned long long)(L.segs);                                                                  \
+                counters[35 + 4 * i_] = ((unsigned long long)(my_slot) << 8) | (unsigned long long)(my_pix);                           \
+            }                                                                                                                          \
+        }                                                                                                                              \
+    }
+#define RTK_PROF_QUEUE_EMPTY \
+    if (prof_wall_empty == 0) prof_wall_empty = wall_clock64();
 #define RTK_PROF_MARK(phase, steps, lanes)                           \
     {                                                                \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
@@ -976,9 +994,23 @@ RTK_DEV int popcount64(unsigned long long m) {
             atomicAdd(&counters[3 * ph_], prof_t[ph_]);                       \
             atomicAdd(&counters[3 * ph_ + 1], prof_n[ph_]);                   \
             atomicAdd(&counters[3 * ph_ + 2], prof_l[ph_]);                   \
-        }
+        }                                                                     \
+    if (lane == 0) { /* wave lifetimes on the 100 MHz wall clock: [18] sum, [19] max, [20] sum of the time after the queue ran dry, [21] its max, [22] waves, [23] 2^62 - first start, [24] last end */ \
+        const unsigned long long end_ = wall_clock64();                       \
+        if (prof_wall_empty == 0) prof_wall_empty = end_;                     \
+        atomicAdd(&counters[18], end_ - prof_wall0);                          \
+        atomicMax(&counters[19], end_ - prof_wall0);                          \
+        atomicAdd(&counters[20], end_ - prof_wall_empty);                     \
+        atomicMax(&counters[21], end_ - prof_wall_empty);                     \
+        atomicAdd(&counters[22], 1ull);                                       \
+        atomicMax(&counters[23], (1ull << 62) - prof_wall0);                  \
+        atomicMax(&counters[24], end_);                                       \
+    }
 #else
 #define RTK_PROF_DECL
+#define RTK_PROF_QUEUE_EMPTY
+#define RTK_PROF_CHUNK_BEGIN
+#define RTK_PROF_CHUNK_END
 #define RTK_PROF_MARK(phase, steps, lanes)
 #define RTK_PROF_FLUSH
 #endif
@@ -1091,6 +1123,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             const int t = int(__builtin_amdgcn_readfirstlane(prefetched_item));
             if (t >= n_items) {
                 exhausted = true;
+                RTK_PROF_QUEUE_EMPTY
                 return false;
             }
             refill_item = t;
@@ -1123,6 +1156,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                 L.s = it_s_begin;
                 L.segs = 0;
                 cost_tile = it_cost_tile;
+                RTK_PROF_CHUNK_BEGIN
                 begin_sample(L, cam, px_i, px_j, seed_hash, cnt);
                 if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0, MIXED>(L, cnt, extent);
                 else L.pc = end_pc;  // max_depth == 0: ray_color returns black at once (Camera.txt:205-206)
@@ -1313,6 +1347,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                         finished = true;
                         alive = false;
                         L.kind = OP_DEAD;
+                        RTK_PROF_CHUNK_END
                         store_partial(partial, my_slot, my_pix, L.sum);
                         if (tile_cost && cost_tile >= 0) atomicAdd(&tile_cost[cost_tile], L.segs);  // no return value: fire and forget
                     }
@@ -1340,6 +1375,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                         L.s = it_s_begin;
                         L.segs = 0;
                         cost_tile = it_cost_tile;
+                        RTK_PROF_CHUNK_BEGIN
                         alive = true;
                         next_sample = true;
                     }

@@ -2,7 +2,7 @@
 -DRTK_PROFILE (s_memtime stamps at the scheduler's phase boundaries), renders one frame and prints,
 per phase: share of wave-cycles, steps, cycles per step, mean active lanes.  Tools only.
 
-  python3 tools/profile_phases.py [config=c2] [real=f64] [spp=0] [order=auto|reference|fast] [variant=0]
+  python3 tools/profile_phases.py [config=c2] [real=f64] [spp=0] [order=auto|reference|fast] [variant=0] [rank=0] [n_ranks=1]
 """
 import os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,6 +22,8 @@ real = rt.RTK_REAL_F64 if (len(sys.argv) <= 2 or sys.argv[2] == "f64") else rt.R
 spp = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 order = sys.argv[4] if len(sys.argv) > 4 else "auto"
 variant = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+rank = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+n_ranks = int(sys.argv[7]) if len(sys.argv) > 7 else 1
 tmp = tempfile.mkdtemp()
 earth = rt.write_synthetic_earth(os.path.join(tmp, "earth_synth.ppm"))
 scene = rt.Scene.build(rt.CONFIG_SCENES[config], rt.SCENE_SEED, earth)
@@ -33,13 +35,13 @@ r.upload_fast(scene, cam.center) if use_fast else r.upload(scene)
 print("order:", "fast" if use_fast else "reference")
 dev = torch.device("cuda", 0)
 H, W = cam.image_height, cam.image_width
-img = torch.empty((H, W, 3), dtype=torch.float64 if real == rt.RTK_REAL_F64 else torch.float32, device=dev)
-prof = torch.zeros(18, dtype=torch.int64, device=dev)
+img = torch.empty((H, W, 3), dtype=torch.float64 if real == rt.RTK_REAL_F64 else torch.float32, device=dev)  # large enough for any shard
+prof = torch.zeros(32 + 4 * 4096, dtype=torch.int64, device=dev)
 # the profile build writes its counters through the d_counters pointer of the (non-counting) kernel
 lib = rt.hip_lib()
 import ctypes as C
-opts = rt.RenderOpts(rt.RENDER_SEED, real, 0, 1, 0, variant, torch.cuda.current_stream().cuda_stream)
-for k in range(2):
+opts = rt.RenderOpts(rt.RENDER_SEED, real, rank, n_ranks, 0, variant, torch.cuda.current_stream().cuda_stream)
+for k in range(3):
     prof.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -47,7 +49,8 @@ for k in range(2):
     assert rc == 0, lib.rtk_last_error()
     e1.record(); e1.synchronize()
 ms = e0.elapsed_time(e1)
-v = prof.cpu().numpy().reshape(6, 3).astype(float)
+raw = prof.cpu().numpy()
+v = raw[:18].reshape(6, 3).astype(float)
 total = v[:, 0].sum()
 names = ["refill+vote", "box step", "sphere step", "shade+regen", "other op", "quad/tri step"]
 print(f"{config} {'f64' if real == rt.RTK_REAL_F64 else 'f32'} {W}x{H}x{cam.samples_per_pixel}: {ms:.2f} ms (instrumented)")
@@ -55,3 +58,19 @@ print(f"{'phase':14s} {'cycles %':>9s} {'steps':>14s} {'cyc/step':>9s} {'lanes/s
 for n, (t, steps, lanes) in zip(names, v):
     if steps:
         print(f"{n:14s} {100 * t / total:9.1f} {int(steps):14d} {t / steps:9.1f} {lanes / steps:10.1f}")
+waves = int(raw[22])
+if waves:
+    span = (int(raw[24]) - ((1 << 62) - int(raw[23]))) / 100.0   # us
+    print(f"waves {waves}: kernel span {span:.1f} us; wave lifetime mean {raw[18] / waves / 100.0:.1f} us ({100 * raw[18] / waves / 100.0 / span:.1f} % of the span), max {raw[19] / 100.0:.1f} us; "
+          f"after the work queue ran dry: mean {raw[20] / waves / 100.0:.1f} us, max {raw[21] / 100.0:.1f} us")
+    first = (1 << 62) - int(raw[23])
+    n_long = int(raw[31])
+    recs = raw[32:32 + 4 * min(n_long, 4096)].reshape(-1, 4)
+    print(f"(pixel, chunk)s that ended after the work queue ran dry and took over 300 us: {n_long}")
+    if len(recs):
+        ends = recs[:, 0] + recs[:, 1]
+        for i in ends.argsort()[::-1][:16]:
+            b, dur, segs, where = (int(x) for x in recs[i])
+            print(f"   began {(b - first) / 100.0:9.1f} us  took {dur / 100.0:8.1f} us  ended {(b + dur - first) / 100.0:9.1f} us  segments {segs:5d}  slot {where >> 8} pixel {where & 255}")
+        import numpy as np
+        print(f"   durations: median {np.median(recs[:, 1]) / 100.0:.1f} us, max {recs[:, 1].max() / 100.0:.1f} us; segments median {np.median(recs[:, 2]):.0f}, max {recs[:, 2].max()}")

@@ -8,7 +8,10 @@ configs[1]), on N MI355X GPUs of one node.
 
 A "step" is one full render of the image: every rank renders its interleaved 8x8
 tiles (no collective while rendering), then ONE gather of the compact tile buffers
-to rank 0 over RCCL/xGMI and the un-permute kernel there.  Inputs (scene, camera)
+to rank 0 over RCCL/xGMI and the un-permute kernel there.  The gather of frame k runs
+while frame k+1 renders (two tile buffers per rank, tiling.GatherPipeline); all K frames
+are rendered, gathered and un-permuted inside the timed region (--sync-gather: each frame
+is gathered before the next one starts).  Inputs (scene, camera)
 are resident in HBM before the timed region; the framebuffer stays on the device.
 value = W*H*spp*K / max-over-ranks(time) / 1e6, whole job.  Total work is fixed as
 N grows, so scaling is "strong".
@@ -65,6 +68,7 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-f32", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
+    p.add_argument("--sync-gather", action="store_true", help="N > 1: gather each frame before the next one is rendered (no overlap; dev A/B)")
     p.add_argument("--rehearse-one-gpu", action="store_true",
                    help="dev only: run all ranks on device 0 with a gloo gather through host memory, to rehearse the N>1 control flow on a 1-GPU box")
     return p.parse_args()
@@ -166,8 +170,18 @@ def main():
         tpr = tiling.tiles_per_rank(W, H, n)
         image = torch.empty((H, W, 3), dtype=dtype, device=dev) if rank == 0 else None
         rgb8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
-        compact = torch.empty((tpr, 3, 64), dtype=dtype, device=dev) if n > 1 else None
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+        def unpermute(gathered):  # rank 0: [n, tiles_per_rank, 3, 64] -> the row-major image + bytes
+            if gathered.device != dev:  # gloo rehearsal: the gather went through host memory
+                gathered = gathered.to(dev)
+            renderer.unpermute(W, H, n, real_mode, gathered.data_ptr(), image.data_ptr(), rgb8.data_ptr(), stream=stream)
+
+        # N > 1: two compact tile buffers per rank; the gather of frame k runs while frame k+1 renders (tiling.GatherPipeline)
+        pipe = None
+        if n > 1 and not args.sync_gather:
+            pipe = tiling.GatherPipeline(n, rank, lambda: torch.empty((tpr, 3, 64), dtype=dtype, device=dev), unpermute, stage_to_host=args.rehearse_one_gpu)
+        compact = torch.empty((tpr, 3, 64), dtype=dtype, device=dev) if (n > 1 and pipe is None) else None
 
         def step(kernel_ms=None):
             if kernel_ms is not None:
@@ -175,21 +189,27 @@ def main():
             if n == 1:
                 renderer.render_device(cam, image.data_ptr(), rgb8.data_ptr(), real_mode=real_mode, variant=args.variant, stream=stream)
             else:
-                renderer.render_device(cam, compact.data_ptr(), 0, real_mode=real_mode, rank=rank, n_ranks=n, variant=args.variant, stream=stream)
+                target = pipe.next_buffer() if pipe is not None else compact
+                renderer.render_device(cam, target.data_ptr(), 0, real_mode=real_mode, rank=rank, n_ranks=n, variant=args.variant, stream=stream)
             if kernel_ms is not None:
                 ev[1].record()
-            if n > 1:
+            if pipe is not None:
+                pipe.submit()  # starts this frame's gather, completes the previous frame (gather wait + un-permute on rank 0)
+            elif n > 1:
                 if args.rehearse_one_gpu:  # gloo has no device gather: stage through host memory (rehearsal only)
-                    host = tiling.gather_to_root(compact.cpu(), n, rank)
-                    gathered = host.to(dev) if rank == 0 else None
+                    gathered = tiling.gather_to_root(compact.cpu(), n, rank)
                 else:
                     gathered = tiling.gather_to_root(compact, n, rank)
                 if rank == 0:
-                    renderer.unpermute(W, H, n, real_mode, gathered.data_ptr(), image.data_ptr(), rgb8.data_ptr(), stream=stream)
+                    unpermute(gathered)
             if kernel_ms is not None:
                 ev[1].synchronize()
                 kernel_ms.append(ev[0].elapsed_time(ev[1]))
-        return step, image
+
+        def flush():  # completes the frame still in flight; part of the timed region
+            if pipe is not None:
+                pipe.flush()
+        return step, flush, image
 
     def barrier():
         if n > 1:
@@ -197,13 +217,15 @@ def main():
         torch.cuda.synchronize()
 
     def timed(real_mode, steps, warmup, renderer=renderer):
-        step, image = make_step(real_mode, renderer)
+        step, flush, image = make_step(real_mode, renderer)
         for _ in range(warmup):
             step()
+        flush()
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        flush()
         barrier()
         elapsed = time.perf_counter() - t0
         if n > 1:
@@ -214,6 +236,7 @@ def main():
         kernel_ms = []
         for _ in range(min(steps, 5)):
             step(kernel_ms)
+        flush()
         barrier()
         return elapsed, sum(kernel_ms) / len(kernel_ms), image
 
@@ -318,7 +341,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{scene_name} {W}x{H}x{spp}spp depth {depth} (BASELINE configs[{int(args.config[1]) - 1}])",
-                       "tiles": "8x8 px per wave, interleaved over ranks", "parallelism": f"image tiles over {n} GPU(s) + 1 gather" if n > 1 else "1 GPU",
+                       "tiles": "8x8 px per wave, interleaved over ranks", "parallelism": (f"image tiles over {n} GPU(s) + 1 gather per frame" + ("" if args.sync_gather else ", overlapped with the next frame")) if n > 1 else "1 GPU",
                        "scene_seed": rt.SCENE_SEED, "render_seed": rt.RENDER_SEED, "program_ops": info["program_ops"], "reduced": reduced,
                        "variant": args.variant, "order": order_name},
             "roofline": roofline,

@@ -75,3 +75,56 @@ def gather_to_root(local, n_ranks: int, rank: int, root: int = 0):
         return out
     dist.gather(local, None, dst=root)
     return None
+
+
+class GatherPipeline:
+    """Frame k's gather overlapped with frame k+1's rendering (N > 1 only).
+
+    Each rank renders into one of two compact tile buffers (``next_buffer``); ``submit`` starts the gather of the
+    buffer just rendered (asynchronously: RCCL runs it on its own stream once the render has finished) and only then
+    completes the PREVIOUS frame -- waits for its gather and, on root, hands the gathered tiles to ``consume`` (the
+    un-permute kernel).  The render of frame k+1 is therefore enqueued without waiting for gather k; a buffer is
+    rewritten two frames later, after its gather has been waited for.  ``flush`` completes the last frame.  Which
+    frame is gathered when never changes a pixel.
+
+    ``stage_to_host``: gather host copies (gloo rehearsal of CUDA buffers on one GPU, CPU tests)."""
+
+    def __init__(self, n_ranks: int, rank: int, make_buffer, consume, root: int = 0, stage_to_host: bool = False):
+        self.n_ranks, self.rank, self.root = n_ranks, rank, root
+        self.buffers = [make_buffer(), make_buffer()]
+        self.consume = consume
+        self.stage_to_host = stage_to_host
+        self.pending = None
+        self.frame = 0
+
+    def next_buffer(self):
+        return self.buffers[self.frame & 1]
+
+    def submit(self):
+        import torch
+        import torch.distributed as dist
+
+        local = self.buffers[self.frame & 1]
+        if self.stage_to_host:
+            local = local.cpu()
+        out = None
+        if self.rank == self.root:
+            out = torch.empty((self.n_ranks,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+            work = dist.gather(local, list(out.unbind(0)), dst=self.root, async_op=True)
+        else:
+            work = dist.gather(local, None, dst=self.root, async_op=True)
+        previous, self.pending = self.pending, (out, work, local)
+        self.frame += 1
+        self._finish(previous)
+
+    def flush(self):
+        previous, self.pending = self.pending, None
+        self._finish(previous)
+
+    def _finish(self, entry):
+        if entry is None:
+            return
+        out, work, _keep_alive = entry
+        work.wait()  # device tensors: the current stream waits for the collective; host tensors: this thread does
+        if self.rank == self.root:
+            self.consume(out)

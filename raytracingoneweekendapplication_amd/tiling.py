@@ -80,40 +80,57 @@ def gather_to_root(local, n_ranks: int, rank: int, root: int = 0):
 class GatherPipeline:
     """Frame k's gather overlapped with frame k+1's rendering (N > 1 only).
 
-    Each rank renders into one of two compact tile buffers (``next_buffer``); ``submit`` starts the gather of the
-    buffer just rendered (asynchronously: RCCL runs it on its own stream once the render has finished) and only then
-    completes the PREVIOUS frame -- waits for its gather and, on root, hands the gathered tiles to ``consume`` (the
-    un-permute kernel).  The render of frame k+1 is therefore enqueued without waiting for gather k; a buffer is
-    rewritten two frames later, after its gather has been waited for.  ``flush`` completes the last frame.  Which
-    frame is gathered when never changes a pixel.
+    Each rank renders frame k into compact tile buffer ``k & 1`` (``next_buffer``); ``submit`` starts the gather of
+    the buffer just rendered (asynchronously: RCCL runs it on its own stream once the render has finished) and only
+    then completes the PREVIOUS frame -- waits for its gather and, on root, hands the gathered tiles to
+    ``consume(gathered, slot)`` (the un-permute kernel).  The render of frame k+1 is therefore enqueued without
+    waiting for gather k; a buffer is rewritten two frames later, after its gather has been waited for.  ``flush``
+    completes the last frame.  Which frame is gathered when never changes a pixel.
 
-    ``stage_to_host``: gather host copies (gloo rehearsal of CUDA buffers on one GPU, CPU tests)."""
+    ``streams``: optionally one torch stream per slot (frame k is rendered on ``streams[k & 1]``): the gather of a
+    frame is started, waited for and consumed under ITS stream, so that the other stream's next render never waits
+    for it.  ``stage_to_host``: gather host copies (gloo rehearsal of CUDA buffers on one GPU, CPU tests)."""
 
-    def __init__(self, n_ranks: int, rank: int, make_buffer, consume, root: int = 0, stage_to_host: bool = False):
+    def __init__(self, n_ranks: int, rank: int, make_buffer, consume, root: int = 0, stage_to_host: bool = False, streams=None):
         self.n_ranks, self.rank, self.root = n_ranks, rank, root
         self.buffers = [make_buffer(), make_buffer()]
         self.consume = consume
         self.stage_to_host = stage_to_host
+        self.streams = streams
         self.pending = None
         self.frame = 0
 
+    def slot(self) -> int:
+        return self.frame & 1
+
     def next_buffer(self):
         return self.buffers[self.frame & 1]
+
+    def _on_stream(self, slot: int):
+        import contextlib
+
+        import torch
+
+        if self.streams is None or self.streams[slot] is None:
+            return contextlib.nullcontext()
+        return torch.cuda.stream(self.streams[slot])
 
     def submit(self):
         import torch
         import torch.distributed as dist
 
-        local = self.buffers[self.frame & 1]
-        if self.stage_to_host:
-            local = local.cpu()
-        out = None
-        if self.rank == self.root:
-            out = torch.empty((self.n_ranks,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-            work = dist.gather(local, list(out.unbind(0)), dst=self.root, async_op=True)
-        else:
-            work = dist.gather(local, None, dst=self.root, async_op=True)
-        previous, self.pending = self.pending, (out, work, local)
+        slot = self.frame & 1
+        with self._on_stream(slot):
+            local = self.buffers[slot]
+            if self.stage_to_host:
+                local = local.cpu()
+            out = None
+            if self.rank == self.root:
+                out = torch.empty((self.n_ranks,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+                work = dist.gather(local, list(out.unbind(0)), dst=self.root, async_op=True)
+            else:
+                work = dist.gather(local, None, dst=self.root, async_op=True)
+        previous, self.pending = self.pending, (out, work, local, slot)
         self.frame += 1
         self._finish(previous)
 
@@ -124,7 +141,8 @@ class GatherPipeline:
     def _finish(self, entry):
         if entry is None:
             return
-        out, work, _keep_alive = entry
-        work.wait()  # device tensors: the current stream waits for the collective; host tensors: this thread does
-        if self.rank == self.root:
-            self.consume(out)
+        out, work, _keep_alive, slot = entry
+        with self._on_stream(slot):
+            work.wait()  # device tensors: the slot's stream waits for the collective; host tensors: this thread does
+            if self.rank == self.root:
+                self.consume(out, slot)

@@ -65,7 +65,7 @@ def _pipeline_worker(rank, world, port, image, width, height, n_frames, result):
         tpr = tiling.tiles_per_rank(width, height, world)
         frames = []
         pipe = tiling.GatherPipeline(world, rank, lambda: torch.zeros((tpr, 3, 64), dtype=torch.float64),
-                                     lambda gathered: frames.append(tiling.image_from_gathered(gathered.numpy().copy(), width, height, world)))
+                                     lambda gathered, slot: frames.append((slot, tiling.image_from_gathered(gathered.numpy().copy(), width, height, world))))
         for k in range(n_frames):
             buf = pipe.next_buffer()
             buf.copy_(torch.from_numpy(tiling.compact_from_image(image * (k + 1), rank, world)))  # "render" frame k
@@ -96,5 +96,6 @@ def test_pipelined_gather_delivers_every_frame_in_order(rt, orc):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert len(frames) == n_frames
-    for k, frame in enumerate(frames):
+    for k, (slot, frame) in enumerate(frames):
+        assert slot == (k & 1)
         assert np.array_equal(frame, image * (k + 1))

@@ -11,10 +11,12 @@ tiles (no collective while rendering), then ONE gather of the compact tile buffe
 to rank 0 over RCCL/xGMI and the un-permute kernel there.  The gather of frame k runs
 while frame k+1 renders (two tile buffers per rank, tiling.GatherPipeline); all K frames
 are rendered, gathered and un-permuted inside the timed region (--sync-gather: each frame
-is gathered before the next one starts).  Frames alternate between two contexts on two streams
-(--frames-in-flight 2, the default), so that the end of frame k -- a few long paths on
-otherwise idle CUs -- overlaps the start of frame k+1; every context renders one untimed
-frame first (it learns its tile hand-out order from it).  Inputs (scene, camera)
+is gathered before the next one starts).  On several GPUs frames alternate between two
+contexts on two streams (--frames-in-flight 2), so that the end of frame k -- a few long paths
+on otherwise idle CUs, a sixth of an eighth of the frame -- overlaps the start of frame k+1;
+every context renders one untimed frame first (it learns its tile hand-out order from it).
+On one GPU the default is one stream (the overlap is worth 1 % there, and kernel durations
+in a rocprofv3 trace of the command stay those of single launches).  Inputs (scene, camera)
 are resident in HBM before the timed region; the framebuffer stays on the device.
 value = W*H*spp*K / max-over-ranks(time) / 1e6, whole job.  Total work is fixed as
 N grows, so scaling is "strong".
@@ -71,8 +73,9 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-f32", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
-    p.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2],
-                   help="2 (default): frames alternate between two contexts and streams, so the end of one frame overlaps the start of the next; 1: one stream")
+    p.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2],
+                   help="2: frames alternate between two contexts and streams, so the end of one frame overlaps the start of the next; "
+                        "1: one stream; 0 (default): 1 on one GPU (kernel durations in a rocprofv3 trace of this command then equal roofline.kernel_ms), 2 on several")
     p.add_argument("--sync-gather", action="store_true", help="N > 1: gather each frame before the next one is rendered (no overlap; dev A/B)")
     p.add_argument("--rehearse-one-gpu", action="store_true",
                    help="dev only: run all ranks on device 0 with a gloo gather through host memory, to rehearse the N>1 control flow on a 1-GPU box")
@@ -173,6 +176,8 @@ def main():
     # Two frames in flight: frames alternate between two contexts (own workspace, work counter and learned tile order)
     # on two streams, so that the drain of frame k -- a few long paths on otherwise idle CUs -- overlaps the start of
     # frame k+1 (measured at kernel level: +1 % at N = 1, +6 % on an eighth of the frame; tools/overlap_probe.py).
+    if args.frames_in_flight == 0:
+        args.frames_in_flight = 1 if n == 1 else 2
     main_renderers = [renderer]
     if args.frames_in_flight == 2:
         second = rt.Renderer(local_rank)

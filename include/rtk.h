@@ -202,7 +202,8 @@ typedef struct rtk_render_opts {
                              * 2 = one sample chunk per pixel; 4 = fixed row-major tile order (no cost-ordered
                              * hand-out); bits 3-4 = chunk size (0: 8 samples, 1: 4, 2: 2, 3: 16);
                              * bits 8-13 = scheduler loop-exit thresholds, bits 14-16 = refill batch size, bits 17-19 = lanes needed
-                             * for a sphere step inside the box loop (see csrc/rtk_trace.hip) */
+                             * for a sphere step inside the box loop, bit 20 = f64 boxes instead of the MIXED program, bit 21 = no boxes-in-LDS
+                             * kernel for programs larger than LDS (see csrc/rtk_trace.hip) */
     void* stream;           /* hipStream_t, NULL = default stream */
 } rtk_render_opts;
 

@@ -517,6 +517,39 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
     out.view.program_mixed = nullptr;
     out.view.n_units = 0;
     out.view.extent = 0.0f;
+    // Programs that cannot be staged in LDS whole: the box slots alone, with the tables that find them (F_LDS_BOXES).
+    out.view.box_cache = nullptr;
+    out.view.kind_words = nullptr;
+    out.view.box_rank = nullptr;
+    out.view.n_cached_boxes = out.view.n_kind_words = out.view.n_rank_words = 0;
+    if (slots.size() * sizeof(Slot<real>) + mats.size() * sizeof(MaterialRec<real>) > size_t(kLdsBytesPerCU)) {
+        std::vector<Slot<real>> boxes;
+        std::vector<uint32_t> kind_words((slots.size() + 7) / 8, 0u);
+        std::vector<uint2> rank((slots.size() + 31) / 32, uint2{0u, 0u});
+        for (size_t pc = 0; pc < slots.size();) {
+            const uint32_t kind = slots[pc].kind_payload & 15u;
+            kind_words[pc >> 3] |= kind << ((pc & 7) * 4);
+            if (kind == OP_BOX) {
+                rank[pc >> 5].x |= 1u << (pc & 31);
+                boxes.push_back(slots[pc]);
+            }
+            pc += size_t(slots_of<real>(kind));
+        }
+        uint32_t before = 0;
+        for (auto& r : rank) {
+            r.y = before;
+            before += uint32_t(__builtin_popcount(r.x));
+        }
+        const size_t bytes = boxes.size() * sizeof(Slot<real>) + kind_words.size() * 4 + rank.size() * 8;
+        if (!boxes.empty() && bytes + 64 <= size_t(kLdsBytesPerCU)) {
+            if ((rc = out.upload(boxes, &out.view.box_cache)) != RTK_OK) return rc;
+            if ((rc = out.upload(kind_words, &out.view.kind_words)) != RTK_OK) return rc;
+            if ((rc = out.upload(rank, &out.view.box_rank)) != RTK_OK) return rc;
+            out.view.n_cached_boxes = int32_t(boxes.size());
+            out.view.n_kind_words = int32_t(kind_words.size());
+            out.view.n_rank_words = int32_t(rank.size());
+        }
+    }
     if constexpr (sizeof(real) == 8) {
         if (want_mixed) {
             std::vector<MixedHead> units;
@@ -782,7 +815,7 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
     }
     unsigned char* d_cam = ctx->d_cameras + cslot * kCameraStride;
     const bool allow_lds = (opts->variant & 1) == 0;  // variant bit 0: keep the program in global memory (A/B)
-    const uint32_t diag = uint32_t(opts->variant) & 0x1FFF00u;  // bits 8..20: scheduler policy / program layout A/B used by tools/ only
+    const uint32_t diag = uint32_t(opts->variant) & 0x3FFF00u;  // bits 8..21: scheduler policy / program layout A/B used by tools/ only
     hipError_t e;
     if (opts->real_mode == RTK_REAL_F64) {
         if (!cam_cached) {
@@ -918,7 +951,8 @@ const char* rtk_kernel_name(rtk_ctx* ctx, int real_mode, int variant) {
     const bool f64 = real_mode == RTK_REAL_F64;
     const bool mixed = f64 && ctx->scene64.view.program_mixed != nullptr && (variant & (1 << 20)) == 0;
     const bool lds = (variant & 1) == 0 && (f64 ? program_fits_lds(ctx->scene64.view, mixed) : program_fits_lds(ctx->scene32.view, false));
-    return render_kernel_name(f64, ctx->features, false, lds, mixed);
+    const bool has_box_cache = f64 ? ctx->scene64.view.box_cache != nullptr : ctx->scene32.view.box_cache != nullptr;
+    return render_kernel_name(f64, ctx->features, false, lds, mixed, has_box_cache, uint32_t(variant));
 }
 
 }  // extern "C"

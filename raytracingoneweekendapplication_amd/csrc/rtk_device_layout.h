@@ -28,6 +28,7 @@
 #define RTK_DEVICE_LAYOUT_H
 
 #include <stdint.h>
+#include <hip/hip_vector_types.h>
 
 namespace rtk {
 
@@ -87,6 +88,7 @@ inline constexpr int mixed_units(uint32_t kind) { return kind == OP_SPHERE ? 2 :
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 constexpr int kMaxChain = 4;
 constexpr int kMaxChunks = 64;
+constexpr int kLdsBytesPerCU = 160 * 1024;  // gfx950
 
 // Scene feature bits: which op kinds / shading paths a scene needs.  The host
 // picks the leanest kernel instantiation that covers the scene's mask.
@@ -106,7 +108,10 @@ enum Feature : uint32_t {
     F_F32_BOX = 1u << 8,
     // A restriction, not a feature: every material is a lambertian or a light (the Cornell box).  The quad/box subset
     // kernel then carries no metal / dielectric / isotropic / specular code at all.
-    F_MATTE = 1u << 9
+    F_MATTE = 1u << 9,
+    // Not a scene feature either: the program is too large for LDS but its box records are not -- the kernel stages the
+    // boxes alone (SceneView::box_cache), the per-slot kind nibbles and a rank table in LDS; primitives stay in HBM/L2.
+    F_LDS_BOXES = 1u << 10
 };
 constexpr uint32_t kFeatLean = 0;                       // spheres + lambertian/metal/dielectric with solid colours
 constexpr uint32_t kFeatAll = 0x7F;
@@ -181,6 +186,13 @@ struct SceneView {  // device pointers, passed to the kernel by value
     const MixedHead* program_mixed;
     int32_t n_units;
     float extent;
+    // F_LDS_BOXES (programs larger than LDS; null when the program fits or the boxes do not): the OP_BOX slots in program
+    // order; kind_words[pc >> 3] holds the kind of slot pc in nibble (pc & 7); box_rank[pc >> 5] = {bit per slot that
+    // starts a box, number of boxes before slot 32 * (pc >> 5)} -- cache index of the box at pc = y + popc(x & below(pc)).
+    const Slot<real>* box_cache;
+    const uint32_t* kind_words;
+    const uint2* box_rank;
+    int32_t n_cached_boxes, n_kind_words, n_rank_words;
 };
 
 struct TileMap {  // which tiles this launch renders and where the pixels go

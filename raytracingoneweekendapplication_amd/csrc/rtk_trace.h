@@ -40,7 +40,7 @@ template <typename real>
 hipError_t launch_unpermute(const void* gathered, int width, int height, int n_ranks, long long tiles_per_rank, void* out_linear, uint8_t* out_rgb8,
                             hipStream_t stream);
 
-const char* render_kernel_name(bool f64, uint32_t features, bool count, bool lds, bool mixed);
+const char* render_kernel_name(bool f64, uint32_t features, bool count, bool lds, bool mixed, bool has_box_cache, uint32_t diag);
 
 }  // namespace rtk
 

@@ -1031,17 +1031,20 @@ RTK_DEV void store_partial(real* __restrict__ partial, int item, int pix, V3<rea
 // the full-feature kernel, which needs far more registers (~560 B/lane of spills at 168), is fastest at 2 waves.
 template <typename real, uint32_t FEAT>
 constexpr int max_threads() {
-    constexpr uint32_t scene_feat = FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE);
+    constexpr uint32_t scene_feat = FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE | F_LDS_BOXES);
     if (sizeof(real) == 8) return scene_feat == kFeatAll ? 512 : ((scene_feat == kFeatLean || scene_feat == kFeatQuadBox) ? 1024 : 768);
     return 768;
 }
 
-template <typename real, uint32_t FEAT, bool COUNT, bool IN_LDS>
-__global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel(SceneView<real> sc, const CameraRec<real>* __restrict__ cam_ptr, TileMap tmap, uint32_t seed,
+template <typename real, uint32_t FEAT_ALL, bool COUNT, bool IN_LDS>
+__global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_kernel(SceneView<real> sc, const CameraRec<real>* __restrict__ cam_ptr, TileMap tmap, uint32_t seed,
                                                           real* __restrict__ partial, unsigned long long* __restrict__ counters,
                                                           unsigned int* __restrict__ tile_counter, const int32_t* __restrict__ tile_order,
                                                           unsigned int* __restrict__ tile_cost, uint32_t diag) {
     extern __shared__ __align__(16) unsigned char lds_program[];
+    constexpr uint32_t FEAT = FEAT_ALL & ~uint32_t(F_LDS_BOXES);
+    constexpr bool SPLIT = (FEAT_ALL & F_LDS_BOXES) != 0;  // boxes, kinds and the rank table in LDS; everything else of the program in HBM/L2
+    static_assert(!SPLIT || (!IN_LDS && (FEAT & F_F32_BOX) == 0), "F_LDS_BOXES: for programs that do not fit LDS");
     constexpr bool MIXED = (FEAT & F_F32_BOX) != 0;  // the MIXED program: f32 culling boxes, 32-byte units (f64, sphere-only scenes)
     static_assert(!MIXED || (sizeof(real) == 8 && (FEAT & ~uint32_t(F_F32_BOX)) == kFeatLean && !COUNT), "F_F32_BOX: lean f64 kernels only");
     using ProgRec = std::conditional_t<MIXED, MixedHead, Slot<real>>;
@@ -1062,6 +1065,32 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
         prog = reinterpret_cast<const ProgRec*>(lds_program);
         mats = reinterpret_cast<const MaterialRec<real>*>(lds_program + size_t(n_prog16) * 16);
     }
+    [[maybe_unused]] const Slot<real>* lds_boxes = nullptr;
+    [[maybe_unused]] const uint32_t* lds_kinds = nullptr;
+    [[maybe_unused]] const uint2* lds_rank = nullptr;
+    if constexpr (SPLIT) {
+        const int n_box16 = sc.n_cached_boxes * int(sizeof(Slot<real>) / 16);
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(sc.box_cache);
+        uint4* dst = reinterpret_cast<uint4*>(lds_program);
+        for (int k = threadIdx.x; k < n_box16; k += blockDim.x) dst[k] = src[k];
+        uint32_t* kdst = reinterpret_cast<uint32_t*>(lds_program + size_t(n_box16) * 16);
+        for (int k = threadIdx.x; k < sc.n_kind_words; k += blockDim.x) kdst[k] = sc.kind_words[k];
+        uint2* rdst = reinterpret_cast<uint2*>(lds_program + size_t(n_box16) * 16 + ((size_t(sc.n_kind_words) * 4 + 7) & ~size_t(7)));
+        for (int k = threadIdx.x; k < sc.n_rank_words; k += blockDim.x) rdst[k] = sc.box_rank[k];
+        __syncthreads();
+        lds_boxes = reinterpret_cast<const Slot<real>*>(lds_program);
+        lds_kinds = kdst;
+        lds_rank = rdst;
+    }
+    // kind of the record that starts at slot pc; the box record at pc (SPLIT: from the LDS copies)
+    auto kind_of = [&](uint32_t pc) -> uint32_t {
+        if constexpr (SPLIT) return (lds_kinds[pc >> 3] >> ((pc & 7u) * 4u)) & 15u;
+        else return prog[pc].kind_payload & 15u;
+    };
+    [[maybe_unused]] auto box_at = [&](uint32_t pc) -> Slot<real> {
+        const uint2 e = lds_rank[pc >> 5];
+        return lds_boxes[e.y + uint32_t(__builtin_popcount(e.x & ((1u << (pc & 31u)) - 1u)))];
+    };
     // The hand-out order of the tiles (learned from the previous frame) is staged behind the program when the host
     // found room for it (tmap.order_in_lds): a lookup per work item from LDS instead of a cold global load.
     const int32_t* lds_order = nullptr;
@@ -1160,7 +1189,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                 begin_sample(L, cam, px_i, px_j, seed_hash, cnt);
                 if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0, MIXED>(L, cnt, extent);
                 else L.pc = end_pc;  // max_depth == 0: ray_color returns black at once (Camera.txt:205-206)
-                L.kind = prog[L.pc].kind_payload & 15u;
+                L.kind = kind_of(L.pc);
             }
         }
         const int n_idle = popcount64(m_idle);
@@ -1227,8 +1256,24 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
 #define RTK_UNROLL_MIXED 8
 #endif
             constexpr int kBoxUnroll = (MIXED || FEAT == (kFeatLean | uint32_t(F_FMA_BOX))) ? RTK_UNROLL_MIXED : ((FEAT & ~uint32_t(F_FMA_BOX)) == kFeatAll ? 2 : 1);
-            ProgRec cur = prog[L.pc];  // the record at L.pc (its first 32 bytes in the MIXED layout), held in registers: one LDS round trip per step
+            ProgRec cur;  // the record at L.pc (its first 32 bytes in the MIXED layout), held in registers: one LDS round trip per step
             uint32_t k = kind;
+            // the record at L.pc -> cur, its kind -> k.  SPLIT: the kind comes from the LDS nibble table and only boxes are
+            // fetched (from the LDS copy); a primitive's record is read from memory by the step that tests it
+            auto fetch = [&]() {
+                if constexpr (SPLIT) {
+                    k = kind_of(L.pc);
+                    if (k == OP_BOX) cur = box_at(L.pc);
+                } else {
+                    cur = prog[L.pc];
+                    k = cur.kind_payload & 15u;
+                }
+            };
+            if constexpr (SPLIT) {
+                if (k == OP_BOX) cur = box_at(L.pc);
+            } else {
+                cur = prog[L.pc];
+            }
             const uint32_t box_kind = L.box_kind;  // a lane with an irregular ray matches nothing here: it never steps in this loop
             int remaining;
             // Sphere tests ride along: whenever `sphere_min` lanes of the wave sit on a sphere record, they are
@@ -1239,8 +1284,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                 if (k == box_kind) {
                     if constexpr (MIXED) step_box32(L, cur, cnt);
                     else step_box<false, (FEAT & F_XFORM) != 0, (FEAT & F_FMA_BOX) != 0>(L, cur, cnt);
-                    cur = prog[L.pc];
-                    k = cur.kind_payload & 15u;
+                    fetch();
                     L.kind = k;
                 }
 #pragma unroll
@@ -1250,17 +1294,16 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                     if (k == box_kind) {
                         if constexpr (MIXED) step_box32(L, cur, cnt);
                         else step_box<false, (FEAT & F_XFORM) != 0, (FEAT & F_FMA_BOX) != 0>(L, cur, cnt);
-                        cur = prog[L.pc];
-                        k = cur.kind_payload & 15u;
+                        fetch();
                         L.kind = k;
                     }
                 }
                 if (popcount64(__ballot(k == OP_SPHERE)) >= sphere_min) {
                     if (k == OP_SPHERE) {
+                        if constexpr (SPLIT) cur = prog[L.pc];
                         if constexpr (MIXED) step_sphere_mixed(L, cur, prog + L.pc, cnt);
                         else step_sphere<(FEAT & F_XFORM) != 0>(L, cur, cnt);
-                        cur = prog[L.pc];
-                        k = cur.kind_payload & 15u;
+                        fetch();
                         L.kind = k;
                     }
                     RTK_PROF_MARK(2, 1, 0)
@@ -1280,8 +1323,13 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                 if (k == OP_SPHERE) {
                     if constexpr (MIXED) step_sphere_mixed(L, cur, prog + L.pc, cnt);
                     else step_sphere<(FEAT & F_XFORM) != 0>(L, cur, cnt);
-                    cur = prog[L.pc];
-                    k = cur.kind_payload & 15u;
+                    if constexpr (SPLIT) {
+                        k = kind_of(L.pc);
+                        if (k == OP_SPHERE) cur = prog[L.pc];
+                    } else {
+                        cur = prog[L.pc];
+                        k = cur.kind_payload & 15u;
+                    }
                     L.kind = k;
                 }
                 remaining = popcount64(__ballot(k == OP_SPHERE));
@@ -1302,7 +1350,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                         L.best_pc = L.pc;
                     }
                     L.pc += 3;
-                    k = prog[L.pc].kind_payload & 15u;
+                    k = kind_of(L.pc);
                     L.kind = k;
                 }
                 remaining = popcount64(__ballot(k == OP_QUAD));
@@ -1325,7 +1373,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
                         L.best_pc = L.pc;
                     }
                     L.pc += 2;
-                    k = prog[L.pc].kind_payload & 15u;
+                    k = kind_of(L.pc);
                     L.kind = k;
                 }
                 remaining = popcount64(__ballot(k == OP_TRI));
@@ -1388,14 +1436,14 @@ __global__ __launch_bounds__((max_threads<real, FEAT>())) void rtk_render_kernel
             if (alive) {
                 if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0, MIXED>(L, cnt, extent);
                 else L.pc = end_pc;
-                L.kind = prog[L.pc].kind_payload & 15u;
+                L.kind = kind_of(L.pc);
             }
             RTK_PROF_MARK(3, 1, n_shd)
         } else {
             if (m_oth >> lane & 1ull) {
                 if constexpr (MIXED) step_other_mixed(L, prog + L.pc, cnt);
                 else step_other<real, FEAT, COUNT>(L, prog + L.pc, sc, cnt);
-                L.kind = prog[L.pc].kind_payload & 15u;
+                L.kind = kind_of(L.pc);
             }
             RTK_PROF_MARK(4, 1, n_oth)
         }
@@ -1578,7 +1626,6 @@ __global__ __launch_bounds__(256) void rtk_unpermute_kernel(const real* __restri
 }
 
 // ------------------------------------------------------------------ launchers --
-constexpr int kLdsBytesPerCU = 160 * 1024;
 
 // Geometry of a persistent launch: waves per workgroup and workgroups per CU so
 // that (a) the register-limited wave count per CU is reached and (b) every
@@ -1624,6 +1671,19 @@ static size_t lds_image_bytes(const SceneView<real>& sc, bool mixed = false) {
     return program + size_t(sc.n_materials) * sizeof(MaterialRec<real>);
 }
 
+// F_LDS_BOXES kernels: the box slots, the kind nibbles (padded to 8 bytes) and the rank table.
+template <typename real>
+static size_t split_lds_bytes(const SceneView<real>& sc) {
+    return size_t(sc.n_cached_boxes) * sizeof(Slot<real>) + ((size_t(sc.n_kind_words) * 4 + 7) & ~size_t(7)) + size_t(sc.n_rank_words) * 8;
+}
+// Whether a launch that cannot stage the whole program uses the boxes-in-LDS kernel: the upload built the tables (the
+// program is larger than LDS, its boxes are not) and the kernel family has the instantiation (mesh and full-feature).
+template <typename real>
+static bool use_lds_boxes(const SceneView<real>& sc, uint32_t feat, bool lds, bool count, uint32_t diag) {
+    const uint32_t scene = feat & ~uint32_t(F_FMA_BOX | F_MATTE);
+    return !lds && !count && sc.box_cache != nullptr && (scene == kFeatMesh || scene == kFeatAll) && (diag & (1u << 21)) == 0;
+}
+
 template <typename real, uint32_t FEAT, bool COUNT, bool IN_LDS>
 static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>* cam, const TileMap& tmap, uint32_t seed, void* partial,
                              unsigned long long* counters, unsigned int* tile_counter, const int32_t* tile_order, unsigned int* tile_cost, uint32_t diag,
@@ -1631,7 +1691,7 @@ static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>* c
     const int n_items = tmap.n_tiles_local * tmap.n_chunks;
     if (n_items <= 0) return hipSuccess;
     auto kernel = rtk_render_kernel<real, FEAT, COUNT, IN_LDS>;
-    size_t lds = IN_LDS ? lds_image_bytes(sc, (FEAT & F_F32_BOX) != 0) : 0;
+    size_t lds = IN_LDS ? lds_image_bytes(sc, (FEAT & F_F32_BOX) != 0) : ((FEAT & F_LDS_BOXES) ? split_lds_bytes(sc) : 0);
     // room for the tile order behind the program?  (never at the price of a second resident workgroup's LDS)
     TileMap tm = tmap;
     tm.order_in_lds = 0;
@@ -1680,6 +1740,10 @@ static hipError_t launch_feat(const SceneView<real>& sc, const CameraRec<real>* 
                               hipStream_t stream) {
     if constexpr ((FEAT & ~uint32_t(F_FMA_BOX)) == kFeatAll) {
         if (count) return launch_one<real, FEAT, true, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
+    }
+    if constexpr ((FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatMesh || (FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatAll) {
+        if (use_lds_boxes(sc, FEAT, lds, count, diag))
+            return launch_one<real, FEAT | uint32_t(F_LDS_BOXES), false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
     }
     return lds ? launch_one<real, FEAT, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream)
                : launch_one<real, FEAT, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
@@ -1756,11 +1820,12 @@ hipError_t launch_unpermute(const void* gathered, int width, int height, int n_r
 template hipError_t launch_unpermute<double>(const void*, int, int, int, long long, void*, uint8_t*, hipStream_t);
 template hipError_t launch_unpermute<float>(const void*, int, int, int, long long, void*, uint8_t*, hipStream_t);
 
-const char* render_kernel_name(bool f64, uint32_t features, bool count, bool lds, bool mixed) {
+const char* render_kernel_name(bool f64, uint32_t features, bool count, bool lds, bool mixed, bool has_box_cache, uint32_t diag) {
     static thread_local char name[96];
-    snprintf(name, sizeof name, "rtk_render_kernel<%s, %uu, %s, %s>", f64 ? "double" : "float",
-             kernel_features(f64 ? features : (features & ~uint32_t(F_MATTE)), count, mixed && f64), count ? "true" : "false",
-             (lds && !count) ? "true" : "false");
+    uint32_t feat = kernel_features(f64 ? features : (features & ~uint32_t(F_MATTE)), count, mixed && f64);
+    const uint32_t scene = feat & ~uint32_t(F_FMA_BOX | F_MATTE);
+    if (!lds && !count && has_box_cache && (scene == kFeatMesh || scene == kFeatAll) && (diag & (1u << 21)) == 0) feat |= uint32_t(F_LDS_BOXES);
+    snprintf(name, sizeof name, "rtk_render_kernel<%s, %uu, %s, %s>", f64 ? "double" : "float", feat, count ? "true" : "false", (lds && !count) ? "true" : "false");
     return name;
 }
 

@@ -457,3 +457,31 @@ def test_cpp_camera_render_through_the_drop_in_api(rt, tmp_path):
     assert not fog["exact"] and not fog["auto_used_fast"] and fog["auto_identical"]
     assert abs(fog["mean_fast"] - fog["mean_ref"]) < 0.03 * fog["mean_ref"]
     assert clear["mean_ref"] > 0.05
+
+
+def test_boxes_in_lds_kernel_for_programs_larger_than_lds(rt, orc, renderer, scenes):
+    """F_LDS_BOXES: a program that cannot be staged in LDS whole keeps its box slots, kind nibbles and rank table there;
+    the image is the one the all-in-memory kernel and the counting kernel compute (variant bit 21 switches it off)."""
+    scene = scenes("mesh")                       # 1280 triangles: 295 KB of f64 program, 99 KB of boxes
+    cam = scene.camera(64, 36, 4, 10)
+    for fast in (False, True):
+        renderer.upload_fast(scene, cam.center) if fast else renderer.upload(scene)
+        assert (rt.hip_lib().rtk_kernel_name is not None)
+        with_boxes, plain = renderer.kernel_name(), renderer.kernel_name(variant=1 << 21)
+        assert "false, false" in with_boxes and int(with_boxes.split(",")[1].strip(" u")) == int(plain.split(",")[1].strip(" u")) | 1024
+        a, a8, _ = renderer.render_host(cam)
+        b, b8, _ = renderer.render_host(cam, variant=1 << 21)
+        c, c8, _ = renderer.render_host(cam, count=True)
+        assert np.array_equal(a, b) and np.array_equal(a8, b8) and np.array_equal(a, c)
+    renderer.upload(scene)
+    ref, ref8, _ = orc.render(scene.desc_ptr, cam, RENDER_SEED, 8)
+    a, a8, _ = renderer.render_host(cam)
+    assert rmse(a, ref) < F64_RMSE_BOUND and np.array_equal(a8, ref8)
+    # f32 mode of the book-2 scene (443 KB of f32 program): same arithmetic with and without the LDS copies
+    scene = scenes("book2_final")
+    cam = scene.camera(64, 36, 4, 10)
+    renderer.upload(scene)
+    assert "1151u" in renderer.kernel_name(rt.RTK_REAL_F32) and "127u" in renderer.kernel_name(rt.RTK_REAL_F32, 1 << 21)
+    a, a8, _ = renderer.render_host(cam, real_mode=rt.RTK_REAL_F32)
+    b, b8, _ = renderer.render_host(cam, real_mode=rt.RTK_REAL_F32, variant=1 << 21)
+    assert np.array_equal(a, b) and np.array_equal(a8, b8)

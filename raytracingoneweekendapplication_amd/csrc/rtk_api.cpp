@@ -523,7 +523,7 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
     out.view.box_rank = nullptr;
     out.view.n_cached_boxes = out.view.n_kind_words = out.view.n_rank_words = 0;
     if (slots.size() * sizeof(Slot<real>) + mats.size() * sizeof(MaterialRec<real>) > size_t(kLdsBytesPerCU)) {
-        std::vector<Slot<real>> boxes;
+        std::vector<BoxRec<real>> boxes;
         std::vector<uint32_t> kind_words((slots.size() + 7) / 8, 0u);
         std::vector<uint2> rank((slots.size() + 31) / 32, uint2{0u, 0u});
         for (size_t pc = 0; pc < slots.size();) {
@@ -531,7 +531,10 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
             kind_words[pc >> 3] |= kind << ((pc & 7) * 4);
             if (kind == OP_BOX) {
                 rank[pc >> 5].x |= 1u << (pc & 31);
-                boxes.push_back(slots[pc]);
+                BoxRec<real> b{};
+                for (int k = 0; k < 6; k++) b.v[k] = slots[pc].v[k];
+                b.aux = slots[pc].aux;
+                boxes.push_back(b);
             }
             pc += size_t(slots_of<real>(kind));
         }
@@ -540,7 +543,8 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
             r.y = before;
             before += uint32_t(__builtin_popcount(r.x));
         }
-        const size_t bytes = boxes.size() * sizeof(Slot<real>) + kind_words.size() * 4 + rank.size() * 8;
+        const size_t bytes = boxes.size() * sizeof(BoxRec<real>) + ((kind_words.size() * 4 + 7) & ~size_t(7)) + rank.size() * 8;
+        if (getenv("RTK_DEBUG")) fprintf(stderr, "[rtk] %zu-byte reals: %zu slots, %zu box slots, boxes + tables %zu B\n", sizeof(real), slots.size(), boxes.size(), bytes);
         if (!boxes.empty() && bytes + 64 <= size_t(kLdsBytesPerCU)) {
             if ((rc = out.upload(boxes, &out.view.box_cache)) != RTK_OK) return rc;
             if ((rc = out.upload(kind_words, &out.view.kind_words)) != RTK_OK) return rc;

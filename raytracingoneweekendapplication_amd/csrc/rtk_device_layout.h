@@ -62,6 +62,15 @@ struct alignas(16) Slot {
 };
 static_assert(sizeof(Slot<double>) == 64 && sizeof(Slot<float>) == 32, "slot size");
 
+// A box slot without its header word (F_LDS_BOXES keeps only these in LDS): 56 bytes in f64, so that the 2 570 boxes of
+// the book-2 scene fit one CU's LDS beside the kind and rank tables (64-byte slots would not).
+template <typename real>
+struct alignas(8) BoxRec {
+    real v[6];
+    uint32_t aux, unused;
+};
+static_assert(sizeof(BoxRec<double>) == 56 && sizeof(BoxRec<float>) == 32, "box record size");
+
 template <typename real>
 inline constexpr int slots_of(uint32_t kind) {
     return kind == OP_QUAD ? 3 : ((kind == OP_TRI || kind == OP_SPHERE_MOVING) ? 2 : 1);
@@ -189,7 +198,7 @@ struct SceneView {  // device pointers, passed to the kernel by value
     // F_LDS_BOXES (programs larger than LDS; null when the program fits or the boxes do not): the OP_BOX slots in program
     // order; kind_words[pc >> 3] holds the kind of slot pc in nibble (pc & 7); box_rank[pc >> 5] = {bit per slot that
     // starts a box, number of boxes before slot 32 * (pc >> 5)} -- cache index of the box at pc = y + popc(x & below(pc)).
-    const Slot<real>* box_cache;
+    const BoxRec<real>* box_cache;
     const uint32_t* kind_words;
     const uint2* box_rank;
     int32_t n_cached_boxes, n_kind_words, n_rank_words;

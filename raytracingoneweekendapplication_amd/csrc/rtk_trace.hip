@@ -1065,20 +1065,20 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
         prog = reinterpret_cast<const ProgRec*>(lds_program);
         mats = reinterpret_cast<const MaterialRec<real>*>(lds_program + size_t(n_prog16) * 16);
     }
-    [[maybe_unused]] const Slot<real>* lds_boxes = nullptr;
+    [[maybe_unused]] const BoxRec<real>* lds_boxes = nullptr;
     [[maybe_unused]] const uint32_t* lds_kinds = nullptr;
     [[maybe_unused]] const uint2* lds_rank = nullptr;
     if constexpr (SPLIT) {
-        const int n_box16 = sc.n_cached_boxes * int(sizeof(Slot<real>) / 16);
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(sc.box_cache);
-        uint4* dst = reinterpret_cast<uint4*>(lds_program);
-        for (int k = threadIdx.x; k < n_box16; k += blockDim.x) dst[k] = src[k];
-        uint32_t* kdst = reinterpret_cast<uint32_t*>(lds_program + size_t(n_box16) * 16);
+        const size_t box_bytes = size_t(sc.n_cached_boxes) * sizeof(BoxRec<real>);  // a multiple of 8
+        const uint2* __restrict__ src = reinterpret_cast<const uint2*>(sc.box_cache);
+        uint2* dst = reinterpret_cast<uint2*>(lds_program);
+        for (int k = threadIdx.x; k < int(box_bytes / 8); k += blockDim.x) dst[k] = src[k];
+        uint32_t* kdst = reinterpret_cast<uint32_t*>(lds_program + box_bytes);
         for (int k = threadIdx.x; k < sc.n_kind_words; k += blockDim.x) kdst[k] = sc.kind_words[k];
-        uint2* rdst = reinterpret_cast<uint2*>(lds_program + size_t(n_box16) * 16 + ((size_t(sc.n_kind_words) * 4 + 7) & ~size_t(7)));
+        uint2* rdst = reinterpret_cast<uint2*>(lds_program + box_bytes + ((size_t(sc.n_kind_words) * 4 + 7) & ~size_t(7)));
         for (int k = threadIdx.x; k < sc.n_rank_words; k += blockDim.x) rdst[k] = sc.box_rank[k];
         __syncthreads();
-        lds_boxes = reinterpret_cast<const Slot<real>*>(lds_program);
+        lds_boxes = reinterpret_cast<const BoxRec<real>*>(lds_program);
         lds_kinds = kdst;
         lds_rank = rdst;
     }
@@ -1089,7 +1089,13 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
     };
     [[maybe_unused]] auto box_at = [&](uint32_t pc) -> Slot<real> {
         const uint2 e = lds_rank[pc >> 5];
-        return lds_boxes[e.y + uint32_t(__builtin_popcount(e.x & ((1u << (pc & 31u)) - 1u)))];
+        const BoxRec<real> b = lds_boxes[e.y + uint32_t(__builtin_popcount(e.x & ((1u << (pc & 31u)) - 1u)))];
+        Slot<real> s;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s.v[k] = b.v[k];
+        s.kind_payload = OP_BOX;
+        s.aux = b.aux;
+        return s;
     };
     // The hand-out order of the tiles (learned from the previous frame) is staged behind the program when the host
     // found room for it (tmap.order_in_lds): a lookup per work item from LDS instead of a cold global load.
@@ -1674,7 +1680,7 @@ static size_t lds_image_bytes(const SceneView<real>& sc, bool mixed = false) {
 // F_LDS_BOXES kernels: the box slots, the kind nibbles (padded to 8 bytes) and the rank table.
 template <typename real>
 static size_t split_lds_bytes(const SceneView<real>& sc) {
-    return size_t(sc.n_cached_boxes) * sizeof(Slot<real>) + ((size_t(sc.n_kind_words) * 4 + 7) & ~size_t(7)) + size_t(sc.n_rank_words) * 8;
+    return size_t(sc.n_cached_boxes) * sizeof(BoxRec<real>) + ((size_t(sc.n_kind_words) * 4 + 7) & ~size_t(7)) + size_t(sc.n_rank_words) * 8;
 }
 // Whether a launch that cannot stage the whole program uses the boxes-in-LDS kernel: the upload built the tables (the
 // program is larger than LDS, its boxes are not) and the kernel family has the instantiation (mesh and full-feature).

@@ -477,11 +477,12 @@ def test_boxes_in_lds_kernel_for_programs_larger_than_lds(rt, orc, renderer, sce
     ref, ref8, _ = orc.render(scene.desc_ptr, cam, RENDER_SEED, 8)
     a, a8, _ = renderer.render_host(cam)
     assert rmse(a, ref) < F64_RMSE_BOUND and np.array_equal(a8, ref8)
-    # f32 mode of the book-2 scene (443 KB of f32 program): same arithmetic with and without the LDS copies
+    # the book-2 scene (887 KB of f64 program, 2 570 boxes in 56-byte records): same arithmetic with and without the LDS copies
     scene = scenes("book2_final")
     cam = scene.camera(64, 36, 4, 10)
     renderer.upload(scene)
-    assert "1151u" in renderer.kernel_name(rt.RTK_REAL_F32) and "127u" in renderer.kernel_name(rt.RTK_REAL_F32, 1 << 21)
-    a, a8, _ = renderer.render_host(cam, real_mode=rt.RTK_REAL_F32)
-    b, b8, _ = renderer.render_host(cam, real_mode=rt.RTK_REAL_F32, variant=1 << 21)
-    assert np.array_equal(a, b) and np.array_equal(a8, b8)
+    for real in (rt.RTK_REAL_F64, rt.RTK_REAL_F32):
+        assert "1151u" in renderer.kernel_name(real) and "127u" in renderer.kernel_name(real, 1 << 21)
+        a, a8, _ = renderer.render_host(cam, real_mode=real)
+        b, b8, _ = renderer.render_host(cam, real_mode=real, variant=1 << 21)
+        assert np.array_equal(a, b) and np.array_equal(a8, b8)

@@ -1261,7 +1261,11 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
 #ifndef RTK_UNROLL_MIXED
 #define RTK_UNROLL_MIXED 8
 #endif
-            constexpr int kBoxUnroll = (MIXED || FEAT == (kFeatLean | uint32_t(F_FMA_BOX))) ? RTK_UNROLL_MIXED : ((FEAT & ~uint32_t(F_FMA_BOX)) == kFeatAll ? 2 : 1);
+                        // the boxes-in-LDS kernels: C4 49.9 / 48.2 / 47.8 / 49.7 ms at 1 / 2 / 4 / 8 (64 spp), C5 +0.8 % at 4
+#ifndef RTK_UNROLL_SPLIT
+#define RTK_UNROLL_SPLIT 4
+#endif
+            constexpr int kBoxUnroll = (SPLIT && RTK_UNROLL_SPLIT > 0) ? RTK_UNROLL_SPLIT : ((MIXED || FEAT == (kFeatLean | uint32_t(F_FMA_BOX))) ? RTK_UNROLL_MIXED : ((FEAT & ~uint32_t(F_FMA_BOX)) == kFeatAll ? 2 : 1));
             ProgRec cur;  // the record at L.pc (its first 32 bytes in the MIXED layout), held in registers: one LDS round trip per step
             uint32_t k = kind;
             // the record at L.pc -> cur, its kind -> k.  SPLIT: the kind comes from the LDS nibble table and only boxes are

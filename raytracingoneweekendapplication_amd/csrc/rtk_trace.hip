@@ -1318,6 +1318,50 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                     }
                     RTK_PROF_MARK(2, 1, 0)
                 }
+#ifndef RTK_TRI_RIDE
+#define RTK_TRI_RIDE 16
+#endif
+#ifndef RTK_TRI_RIDE_ALL
+#define RTK_TRI_RIDE_ALL 1
+#endif
+#ifndef RTK_QUAD_RIDE
+#define RTK_QUAD_RIDE 16
+#endif
+                if constexpr ((FEAT & F_TRI) != 0 && (SPLIT || RTK_TRI_RIDE_ALL) && RTK_TRI_RIDE > 0) {
+                    // triangle tests ride along as well (mesh scenes: a bvh leaf is a box and one or two triangles):
+                    // C4 47.8 -> 42.5 ms at 16 lanes (8: 42.8, 24: 43.6)
+                    if (popcount64(__ballot(k == OP_TRI)) >= RTK_TRI_RIDE) {
+                        if (k == OP_TRI) {
+                            cnt.inc(C_TRI);
+                            real t;
+                            float fa, fb, fg;
+                            if (tri_test(prog + L.pc, ray_o<(FEAT & F_XFORM) != 0>(L), ray_d<(FEAT & F_XFORM) != 0>(L), L.tmin, L.best_t, t, fa, fb, fg)) {
+                                L.best_t = t;
+                                L.best_pc = L.pc;
+                            }
+                            L.pc += 2;
+                            fetch();
+                            L.kind = k;
+                        }
+                    }
+                }
+                // ... and quad tests in the quad/box subset kernels (C3 31.9 -> 30.4 ms at 16 lanes, 30.8 at 24); the
+                // full-feature kernel has no registers for it (C5 298 -> 316 ms)
+                if constexpr ((FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatQuadBox && RTK_QUAD_RIDE > 0) {
+                    if (popcount64(__ballot(k == OP_QUAD)) >= RTK_QUAD_RIDE) {
+                        if (k == OP_QUAD) {
+                            cnt.inc(C_QUAD);
+                            real t, al, be;
+                            if (quad_test(prog + L.pc, ray_o<(FEAT & F_XFORM) != 0>(L), ray_d<(FEAT & F_XFORM) != 0>(L), L.tmin, L.best_t, t, al, be)) {
+                                L.best_t = t;
+                                L.best_pc = L.pc;
+                            }
+                            L.pc += 3;
+                            fetch();
+                            L.kind = k;
+                        }
+                    }
+                }
                 remaining = popcount64(__ballot(k == box_kind));
                 RTK_PROF_MARK(1, 1, remaining)
             } while (remaining >= keep);

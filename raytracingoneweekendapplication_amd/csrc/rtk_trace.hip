@@ -1264,6 +1264,10 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                         // the boxes-in-LDS kernels: C4 49.9 / 48.2 / 47.8 / 49.7 ms at 1 / 2 / 4 / 8 (64 spp), C5 +0.8 % at 4
             // the subset kernels, now that their primitive tests ride inside the loop: quad/box (C3) 30.5 / 29.4 / 30.7 ms at
             // 1 / 2 / 4; mesh with the program in LDS (C4 f32) 28.8 / 25.5 / 25.3
+            // the lean kernel with the exact slab test (sphere scenes in the reference order): C2 50.7 / 50.0 / 52.0 ms at 1 / 2 / 4
+#ifndef RTK_UNROLL_LEAN
+#define RTK_UNROLL_LEAN 2
+#endif
 #ifndef RTK_UNROLL_QUADBOX
 #define RTK_UNROLL_QUADBOX 2
 #endif
@@ -1273,7 +1277,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
 #ifndef RTK_UNROLL_SPLIT
 #define RTK_UNROLL_SPLIT 4
 #endif
-            constexpr int kBoxUnroll = (SPLIT && RTK_UNROLL_SPLIT > 0) ? RTK_UNROLL_SPLIT : ((MIXED || FEAT == (kFeatLean | uint32_t(F_FMA_BOX))) ? RTK_UNROLL_MIXED : ((FEAT & ~uint32_t(F_FMA_BOX)) == kFeatAll ? 2 : ((FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatQuadBox ? RTK_UNROLL_QUADBOX : ((FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatMesh ? RTK_UNROLL_MESH : 1))));
+            constexpr int kBoxUnroll = (SPLIT && RTK_UNROLL_SPLIT > 0) ? RTK_UNROLL_SPLIT : ((MIXED || FEAT == (kFeatLean | uint32_t(F_FMA_BOX))) ? RTK_UNROLL_MIXED : ((FEAT & ~uint32_t(F_FMA_BOX)) == kFeatAll ? 2 : ((FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatQuadBox ? RTK_UNROLL_QUADBOX : ((FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatMesh ? RTK_UNROLL_MESH : RTK_UNROLL_LEAN))));
             ProgRec cur;  // the record at L.pc (its first 32 bytes in the MIXED layout), held in registers: one LDS round trip per step
             uint32_t k = kind;
             // the record at L.pc -> cur, its kind -> k.  SPLIT: the kind comes from the LDS nibble table and only boxes are

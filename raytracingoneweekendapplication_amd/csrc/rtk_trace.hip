@@ -1133,7 +1133,11 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
     const int refill_min = kRefillMinTable[(diag >> 14) & 7];
     constexpr int kSphereMinTable[8] = {16, 65, 4, 8, 12, 16, 24, 32};  // variant bits 17..19; 65 = never (spheres only through the vote)
     const int sphere_sel = int(diag >> 17) & 7;
-    const int sphere_min = (sphere_sel == 0 && (FEAT & F_F32_BOX)) ? 12 : kSphereMinTable[sphere_sel];  // the MIXED kernel's sweet spot is 12 (24.5 vs 24.7 ms)
+    // defaults per kernel family (tools/variant_sweep.py): MIXED 12 (24.5 vs 24.7 ms at 16); full-feature 4 (C5 297.3 -> 283.4 ms; 8: 285.7);
+    // mesh subset 8 (C4 +1 %); 16 elsewhere
+    constexpr uint32_t kFamily = FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE);
+    constexpr int kSphereMinDefault = (FEAT & F_F32_BOX) ? 12 : (kFamily == kFeatAll ? 4 : (kFamily == kFeatMesh ? 8 : 16));
+    const int sphere_min = sphere_sel == 0 ? kSphereMinDefault : kSphereMinTable[sphere_sel];
 
     Lane<real> L;
     L.pc = end_pc;
@@ -1251,7 +1255,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             // threshold wins: leaving the loop costs a vote plus an exposed LDS round trip,
             // which is worth more than the lanes that idle for a few extra steps.
             const int sel = int(diag >> 8) & 7;  // tools/: A/B of the loop-exit threshold, in eighths of the starters (0 = default)
-            const int eighths = sel == 0 ? 2 : sel;  // measured on C2 (votes now cost ~2 box steps, spheres ride along): 2/8 of the starters 30.9 ms, 3/8 31.8, 4/8 32.4
+            const int eighths = sel == 0 ? (kFamily == kFeatMesh ? 3 : 2) : sel;  // mesh subset: 3/8 (C4 42.4 -> 41.1 ms)  // measured on C2 (votes now cost ~2 box steps, spheres ride along): 2/8 of the starters 30.9 ms, 3/8 31.8, 4/8 32.4
             const int frac = (n_box * eighths) >> 3;
             const int keep = frac > 8 ? frac : 8;
             // Box steps per trip around the loop's scalar checks.  Measured per kernel (tools/ab): the MIXED sphere kernel

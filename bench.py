@@ -33,11 +33,24 @@ parity bar (RMSE < 1e-4 against the CPU at matched seed) is only meaningful at
 that precision.  The f32 kernel's rate is reported beside it under
 "f32_mode" -- never as `value`.
 
+Launching: `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts
+its own N ranks (a `python -m torch.distributed.run` child process, spawned before this
+process imports torch or touches the GPU) and forwards rank 0's JSON line and exit code.
+
 Extra objects on the JSON line:
-  roofline      HBM-bandwidth roofline of the render kernel: algorithmic bytes per
-                launch (SURVEY.md 8(d) byte model x exact work counters from the
-                counting kernel) / mean kernel duration from HIP events on the
-                launch stream.
+  roofline      what bounds the render kernel is VALU issue on partially filled waves, not
+                HBM (the program is served from LDS: measured HBM traffic is < 1 % of peak).
+                bound = "valu"; achieved = VALU pipe-cycles the launch consumed per second
+                (sum over instruction classes of wave-instructions x issue cycles: 2 for
+                an f32-class, 4 for an f64 wave64 instruction on a SIMD-32) / kernel time;
+                peak = SIMDs x clock; frac = achieved / peak <= 1, with the lane utilisation
+                beside it.  Kernel time is measured live with HIP events on the launch
+                stream; the instruction counts and HBM bytes come from rocprofv3 --pmc
+                passes over THIS command (tools/pmc_collect.sh -> profiles/<round>_pmc_<config>.json),
+                accepted only if that file names the same kernel, workload and kernel-source
+                hash -- a stale file is refused and frac is null.  The SURVEY 8(d)
+                algorithmic-byte model is reported under roofline.hbm_model (a model of bytes
+                touched, served from LDS -- not a fraction of anything).
   cpu_baseline  the reference's own classes (oracle/_ref, kind "reference") or the
                 CPU restatement (kind "port") timed on this box's host cores on a
                 bounded sample of the same workload.  Rank 0, N=1 only.
@@ -56,6 +69,87 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+N_SIMDS = 256 * 4      # 256 CUs x 4 SIMD-32 (MI355X_MICROARCH.md, chip-level parameters)
+MAX_CLOCK_GHZ = 2.4    # max shader clock; the clock held during the profiled launch is GRBM_GUI_ACTIVE / 8 / kernel time
+PMC_ROUND = "r02"
+WORKLOAD_NOTES = {"c4": "; the mesh is a procedural 1280-triangle stand-in for the reference's monkey.obj (a data asset that cannot travel to the GPU box, SURVEY 8(d))",
+                  "c5": "; the earth texture is a procedural 1024x512 RGB8 stand-in for earthmap.jpg"}
+# what the render kernel and the program it executes are built from (rtk_multi.cpp / rtk.h only route calls: not part of the key)
+KERNEL_SOURCES = ("raytracingoneweekendapplication_amd/csrc/rtk_trace.hip", "raytracingoneweekendapplication_amd/csrc/rtk_api.cpp",
+                  "raytracingoneweekendapplication_amd/csrc/rtk_optimize.cpp", "raytracingoneweekendapplication_amd/csrc/rtk_device_layout.h",
+                  "raytracingoneweekendapplication_amd/csrc/rtk_trace.h")
+
+
+def kernel_source_hash():
+    """Identifies the kernel code a PMC profile was taken on: sha256 over the sources librtk_hip.so is built from."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(config, kernel, workload, n_gpus):
+    """The rocprofv3 --pmc record of this config's timed kernel (tools/pmc_collect.sh), or (None, reason) when there is
+    none for exactly this kernel, workload and kernel-source hash."""
+    path = os.path.join(ROOT, "profiles", f"{PMC_ROUND}_pmc_{config}.json")
+    if not os.path.exists(path):
+        return None, f"no profiles/{PMC_ROUND}_pmc_{config}.json"
+    try:
+        rec = json.load(open(path))
+    except Exception as exc:
+        return None, f"unreadable {path}: {exc}"
+    want = {"kernel": kernel, "workload": workload, "n_gpus": n_gpus, "source_hash": kernel_source_hash()}
+    for key, val in want.items():
+        if rec.get(key) != val:
+            return None, f"stale profiles/{PMC_ROUND}_pmc_{config}.json: {key} is {rec.get(key)!r}, this run has {val!r}"
+    return rec, os.path.relpath(path, ROOT)
+
+
+def valu_roofline(rec, kernel_ms):
+    """VALU-issue roofline from PMC instruction counts (per launch) and the live kernel time.
+    A CDNA4 SIMD is 32 lanes wide: a wave64 f32-class instruction occupies the pipe for 2 cycles, an f64 one for 4
+    (MI355X_MICROARCH.md: vector FP64 peak = half the FP32 peak; v_fma_f32 wave64 = 2 cycles on a SIMD-32)."""
+    c = rec["counters"]
+    f64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_TRANS_F64"]
+    valu = c["SQ_INSTS_VALU"]
+    pipe_cycles = 4.0 * f64 + 2.0 * (valu - f64)
+    seconds = kernel_ms * 1e-3
+    clock_ghz = MAX_CLOCK_GHZ
+    if c.get("GRBM_GUI_ACTIVE") and rec.get("kernel_ms_profiled"):
+        clock_ghz = min(MAX_CLOCK_GHZ, c["GRBM_GUI_ACTIVE"] / 8.0 / (rec["kernel_ms_profiled"] * 1e-3) / 1e9)  # held during the profiled launch
+    achieved = pipe_cycles / seconds / 1e9
+    peak = N_SIMDS * MAX_CLOCK_GHZ
+    lane_util = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0) if c.get("SQ_ACTIVE_INST_VALU") else None
+    return {"achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "G VALU pipe-cycles/s", "frac": round(achieved / peak, 4),
+            "valu_lane_utilisation": round(lane_util, 4) if lane_util else None,
+            "useful_lane_frac": round(achieved / peak * lane_util, 4) if lane_util else None,
+            "valu_wave_insts_per_launch": int(valu), "f64_share": round(f64 / valu, 4), "clock_ghz_profiled": round(clock_ghz, 3),
+            "issue_cycles": {"f64": 4, "other": 2}}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1, no launcher): start the N ranks ourselves.  Runs before torch is imported --
+    this process never touches the GPU; it only waits for the child and forwards rank 0's JSON line."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env["RTK_BENCH_CHILD"] = "1"
+    print("+ " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
 
 
 def parse_args():
@@ -72,7 +166,8 @@ def parse_args():
                    help="visiting order: the reference's bvh_node order, rtk_scene_optimize's fast order, or fast where it is bit-identical (auto)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-f32", action="store_true")
-    p.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
+    p.add_argument("--no-other-order", action="store_true", help="skip the untimed render in the other visiting order (profiling runs)")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     p.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2],
                    help="2: frames alternate between two contexts and streams, so the end of one frame overlaps the start of the next; "
                         "1: one stream; 0 (default): 1 on one GPU (kernel durations in a rocprofv3 trace of this command then equal roofline.kernel_ms), 2 on several")
@@ -125,6 +220,13 @@ def cpu_baseline(rt, scene_name, cam, earth, target_seconds):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    if os.environ.get("RTK_BENCH_LAUNCH_ONLY"):  # tests of the launcher on boxes without a GPU: report the rank environment, touch nothing
+        sys.stdout.write(json.dumps({"launch_only": True, "rank": int(os.environ.get("RANK", "0")), "world": int(os.environ.get("WORLD_SIZE", "1")),
+                                     "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "gpus": args.gpus, "master": os.environ.get("MASTER_ADDR")}) + "\n")
+        sys.stdout.flush()  # one write per line: the ranks share the parent's pipe
+        return
     import torch
     import torch.distributed as dist
 
@@ -135,9 +237,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n = args.gpus
-    if world != n:
-        if world == 1 and n > 1:
-            raise SystemExit(f"--gpus {n} needs a launcher: python -m torch.distributed.run --nproc-per-node {n} bench.py --gpus {n} ...")
+    if world != n:  # under a launcher the launcher's world size is the truth
         n = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists for the product)")
@@ -286,74 +386,59 @@ def main():
 
     # ---- the other visiting order, outside the timed region: its rate, and the proof that both orders give the same bytes
     other_steps = max(1, min(args.steps, 3))
-    o_elapsed, o_kernel_ms, o_image = timed(rt.RTK_REAL_F64, other_steps, 1, [other_renderer])
     other = None
-    if rank == 0:
+    if not args.no_other_order:
+        o_elapsed, o_kernel_ms, o_image = timed(rt.RTK_REAL_F64, other_steps, 1, [other_renderer])
+    if rank == 0 and not args.no_other_order:
         o_sum = hashlib.sha256(o_image.cpu().numpy().tobytes()).hexdigest()[:16]
         other = {"order": "reference (bvh.h)" if use_fast else "fast (rtk_scene_upload_fast)", "value": round(samples_per_step * other_steps / o_elapsed / 1e6, 2),
                  "unit": "Msamples/s", "kernel_ms": round(o_kernel_ms, 4), "framebuffer_sha256": o_sum, "identical_framebuffer": o_sum == checksum,
                  "fast_order_exact": fast_scene.exact, "fast_order_info": fast_scene.info}
         if fast_scene.exact and o_sum != checksum:
             raise SystemExit(f"fast order claims bit-identity but the framebuffers differ: {checksum} vs {o_sum}")
-    del o_image
+    if not args.no_other_order:
+        del o_image
 
-    # ---- roofline of the render kernel on rank 0: exact work counters -> algorithmic bytes per launch
+    # ---- roofline of the render kernel on rank 0.  Bound: VALU issue (see the module docstring); the HBM byte model of
+    # SURVEY 8(d) and the PMC-measured HBM traffic are reported beside it.
     roofline = None
     counters = None
+    workload = f"{scene_name} {W}x{H}x{spp}"
     if rank == 0:
         d_cnt = torch.zeros(12, dtype=torch.int64, device=dev)
         tpr = tiling.tiles_per_rank(W, H, n)
         scratch = torch.empty((tpr * 192,), dtype=torch.float64, device=dev) if n > 1 else torch.empty((H, W, 3), dtype=torch.float64, device=dev)
-        renderer.render_device(cam, scratch.data_ptr(), 0, real_mode=rt.RTK_REAL_F64, rank=rank, n_ranks=n, d_counters=d_cnt.data_ptr(), stream=stream)
+        # the counting instantiation of the kernel that was timed (same program, same steps) -- exact integers
+        renderer.render_device(cam, scratch.data_ptr(), 0, real_mode=rt.RTK_REAL_F64, rank=rank, n_ranks=n, d_counters=d_cnt.data_ptr(), variant=args.variant, stream=stream)
         torch.cuda.synchronize()
         counters = dict(zip(rt.COUNTER_FIELDS, [int(v) for v in d_cnt.tolist()]))
-        b_sample = rt.algorithmic_bytes_per_sample(counters, spp, rt.RTK_REAL_F64)
+        kernel = renderer.kernel_name(rt.RTK_REAL_F64, args.variant)
+        mixed = ", 256u," in kernel  # F_F32_BOX: 32-byte f32 culling-box records
+        b_sample = rt.algorithmic_bytes_per_sample(counters, spp, rt.RTK_REAL_F64, f32_boxes=mixed)
         bytes_per_launch = b_sample * counters["samples"]
-        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        # HBM traffic and instruction counts come from separate rocprofv3 --pmc passes (tools/pmc_profile.sh),
-        # committed under profiles/; they are quoted only when they were taken on this exact workload.
-        traffic, issue = None, None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                rec = json.load(open(tfile))
-                if rec.get("workload") == f"{scene_name} {W}x{H}x{spp}" and rec.get("n_gpus") == n and rec.get("dtype") == "f64" and rec.get("order", "reference (bvh.h)") == order_name:
-                    traffic = rec.get("hbm_bytes_per_launch")
-                    # what actually bounds the kernel: VALU instruction issue (one wave-instruction per SIMD per
-                    # ~4 cycles for this f64/select mix), on partially filled waves
-                    simd_cycles = kernel_ms * 1e-3 * 2.4e9 * 1024
-                    issue = {"valu_insts_per_launch": int(rec["SQ_INSTS_VALU"]), "f64_share": round(rec["SQ_INSTS_VALU_F64"] / rec["SQ_INSTS_VALU"], 3),
-                             "valu_lane_utilisation": rec["valu_lane_utilisation"],
-                             "simd_issue_frac_at_4_cycles_per_inst": round(rec["SQ_INSTS_VALU"] * 4 / simd_cycles, 3), "source": "profiles/pmc_traffic.json"}
-            except Exception:
-                traffic, issue = None, None
-        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "kernel": renderer.kernel_name(rt.RTK_REAL_F64, args.variant), "kernel_ms": round(kernel_ms, 4),
-                    "algorithmic_bytes_per_sample": round(b_sample, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                    "compulsory_bytes": info["bytes_f64"] + W * H * 3 * 9, "valu_issue": issue,
-                    "note": "achieved = algorithmic bytes (SURVEY 8(d) model x exact counters) / kernel time; the program is served from LDS, so frac can exceed 1 -- see DESIGN.md section 5.  kernel_ms is one launch alone on the device; with two frames in flight ms_per_step can be lower (the end of a frame overlaps the start of the next)",
-                    "per_sample": {k: round(counters[k] / counters["samples"], 4) for k in rt.COUNTER_FIELDS if k != "samples"}}
-
-    # ---- the achievable HBM bandwidth of THIS device beside the spec peak: a 1 GiB device-to-device copy
-    if rank == 0 and roofline is not None:
-        try:
-            src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
-            dst = torch.empty_like(src)
-            best = None
-            for _ in range(4):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                dst.copy_(src)
-                e1.record()
-                e1.synchronize()
-                ms = e0.elapsed_time(e1)
-                best = ms if best is None else min(best, ms)
-            measured = 2 * src.numel() * 4 / (best * 1e-3) / 1e9
-            roofline["peak_measured"] = round(measured, 1)
-            roofline["frac_of_measured_peak"] = round(roofline["achieved"] / measured, 4)
-            del src, dst
-        except Exception:  # reported, never required
-            roofline["peak_measured"] = None
+        model_gbs = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        hbm_model = {"algorithmic_bytes_per_sample": round(b_sample, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                     "model_GBps": round(model_gbs, 1), "hbm_peak_GBps": HBM_PEAK_GBS, "compulsory_bytes": info["bytes_f64"] + W * H * 3 * 9,
+                     "box_record_bytes": 32 if mixed else 56,
+                     "note": "SURVEY 8(d) byte model x exact work counters of the timed kernel's counting build / kernel time.  A model of bytes "
+                             "touched, NOT HBM traffic and not a roofline fraction: the traversal program is staged in LDS, so model_GBps may exceed hbm_peak_GBps",
+                     "per_sample": {k: round(counters[k] / counters["samples"], 4) for k in rt.COUNTER_FIELDS if k != "samples"}}
+        rec, why = (None, "reduced workload: PMC profiles exist for the full-size configs only") if reduced or args.variant else load_pmc(args.config, kernel, workload, n)
+        roofline = {"bound": "valu", "achieved": None, "peak": round(N_SIMDS * MAX_CLOCK_GHZ, 1), "unit": "G VALU pipe-cycles/s", "frac": None, "traffic": None,
+                    "kernel": kernel, "kernel_ms": round(kernel_ms, 4)}
+        if rec is not None:
+            roofline.update(valu_roofline(rec, kernel_ms))
+            roofline["traffic"] = rec.get("hbm_bytes_per_launch")
+            roofline["hbm_traffic_GBps"] = round(rec["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9, 1) if rec.get("hbm_bytes_per_launch") else None
+            roofline["hbm_frac_of_peak"] = round(roofline["hbm_traffic_GBps"] / HBM_PEAK_GBS, 5) if roofline["hbm_traffic_GBps"] else None
+            roofline["pmc"] = {"source": why, "source_hash": rec["source_hash"], "kernel_ms_profiled": rec.get("kernel_ms_profiled"),
+                               "wait_share": rec.get("wait_share"), "lds_bank_conflict_share": rec.get("lds_bank_conflict_share"),
+                               "vgpr": rec.get("vgpr"), "scratch_bytes_per_lane": rec.get("scratch")}
+        else:
+            roofline["pmc"] = {"source": None, "refused": why}
+        roofline["hbm_model"] = hbm_model
+        roofline["note"] = ("frac = VALU pipe-cycles consumed (PMC wave-instruction counts x 2 cycles, f64 x 4) / (1024 SIMDs x 2.4 GHz x kernel time); "
+                            "useful_lane_frac = frac x VALU lane utilisation.  kernel_ms: HIP events on the launch stream, one launch alone on the device")
 
     f32_mode = None
     if not args.no_f32:
@@ -375,7 +460,7 @@ def main():
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{scene_name} {W}x{H}x{spp}spp depth {depth} (BASELINE configs[{int(args.config[1]) - 1}])",
+            "config": {"workload": f"{scene_name} {W}x{H}x{spp}spp depth {depth} (BASELINE configs[{int(args.config[1]) - 1}])" + WORKLOAD_NOTES.get(args.config, ""),
                        "tiles": "8x8 px per wave, interleaved over ranks", "parallelism": (f"image tiles over {n} GPU(s) + 1 gather per frame" + ("" if args.sync_gather else ", overlapped with the next frame")) if n > 1 else "1 GPU",
                        "scene_seed": rt.SCENE_SEED, "render_seed": rt.RENDER_SEED, "program_ops": info["program_ops"], "reduced": reduced,
                        "variant": args.variant, "order": order_name, "frames_in_flight": args.frames_in_flight},

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RTK_ABI_VERSION 1
+#define RTK_ABI_VERSION 1   /* additions since round 1 are new entry points only; no struct changed */
 
 typedef enum rtk_status {
     RTK_OK = 0,
@@ -243,6 +243,14 @@ int rtk_destroy(rtk_ctx* ctx);
  * and uploads f64 and f32 copies.  Replaces any previously uploaded scene. */
 int rtk_scene_upload(rtk_ctx* ctx, const rtk_scene_desc* scene);
 
+/* Host-only: everything rtk_scene_upload checks before it touches the device --
+ * table indices, texture/material references, node kinds, nesting limits, at
+ * least one primitive reachable from the root -- and the compilation of the
+ * traversal program, without a device (works where there is no GPU).  Returns
+ * the status rtk_scene_upload would return for a malformed description;
+ * *n_program_ops (may be NULL) receives the program length in ops. */
+int rtk_scene_validate(const rtk_scene_desc* scene, int32_t* n_program_ops);
+
 /* Fast visiting order -----------------------------------
  * Host-only pass, no device needed.  Re-groups the SAME primitives of `scene`
  * into a surface-area-heuristic hierarchy with a fixed near-child-first order
@@ -287,6 +295,12 @@ void rtk_scene_optimized_free(rtk_scene_desc* scene);
 int rtk_scene_upload_fast(rtk_ctx* ctx, const rtk_scene_desc* scene, const rtk_optimize_opts* opts,
                           rtk_optimize_info* info /* may be NULL */);
 
+/* Upload a description RETURNED BY rtk_scene_optimize (its boxes carry the pass's margin) with the fused / f32
+ * culling slab tests enabled -- the second half of rtk_scene_upload_fast, for callers that optimise once and
+ * upload to several contexts (rtk_multi_scene_upload_fast does).  `opts` = the options the pass was given
+ * (its eye sizes the f32 culling margin); may be NULL. */
+int rtk_scene_upload_optimized(rtk_ctx* ctx, const rtk_scene_desc* optimized, const rtk_optimize_opts* opts);
+
 /* Number of tiles rank `rank` of `n_ranks` owns for a W x H image, and the
  * element count of its compact tile buffer (tiles * 3 * 64 reals). */
 int64_t rtk_tiles_per_rank(int image_width, int image_height, int n_ranks);
@@ -320,6 +334,60 @@ int rtk_tiles_unpermute(rtk_ctx* ctx, int image_width, int image_height, int n_r
  * be NULL.  counters may be NULL. */
 int rtk_render_host(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts* opts,
                     double* h_linear, uint8_t* h_rgb8, rtk_work_counters* counters);
+
+/* Several GPUs behind one call --------------------------------------------------
+ * camera::render owns all parallelism in the reference (std::async row blocks,
+ * Camera.txt:59-61,96-100); rtk_multi is that on the GPUs of one node, driven by
+ * ONE host thread: the scene is replicated, device i renders the interleaved tiles
+ * (t % n == i) into its compact tile buffer on its own stream, ONE gather brings
+ * the buffers to the first device -- a single RCCL ncclGather over xGMI
+ * (rccl.h:745; librccl is loaded on demand) or, when a device is listed more than
+ * once or RCCL is unavailable, one peer copy per device issued on the producing
+ * device's stream -- and rtk_tiles_unpermute there writes the row-major image.
+ * No other exchange exists: every (pixel, sample) is independent.  The image is
+ * bit-identical for any device count (per-sample RNG streams, fixed sample
+ * chunks).  `devices` are HIP ordinals; an ordinal may repeat (two ranks then share
+ * a GPU: used by tests on one-GPU boxes). */
+typedef struct rtk_multi rtk_multi;
+
+typedef enum rtk_gather_mode {
+    RTK_GATHER_AUTO = 0,   /* RCCL when every device is distinct and librccl loads, else peer copies */
+    RTK_GATHER_PEER = 1,   /* hipMemcpyPeerAsync from each device's stream */
+    RTK_GATHER_RCCL = 2    /* ncclGather; rtk_init_multi fails if RCCL cannot be set up */
+} rtk_gather_mode;
+
+int rtk_init_multi(int n_devices, const int* devices, int gather_mode, rtk_multi** out_multi);
+int rtk_multi_destroy(rtk_multi* multi);
+int rtk_multi_device_count(const rtk_multi* multi);
+/* 1 when the gather runs through RCCL, 0 for peer copies. */
+int rtk_multi_uses_rccl(const rtk_multi* multi);
+/* The context bound to device slot i (owned by `multi`; for rtk_scene_info / rtk_kernel_name). */
+rtk_ctx* rtk_multi_ctx(rtk_multi* multi, int i);
+/* Replicated upload.  The _fast form runs rtk_scene_optimize ONCE on the host and uploads
+ * its output to every device. */
+int rtk_multi_scene_upload(rtk_multi* multi, const rtk_scene_desc* scene);
+int rtk_multi_scene_upload_fast(rtk_multi* multi, const rtk_scene_desc* scene, const rtk_optimize_opts* opts,
+                                rtk_optimize_info* info /* may be NULL */);
+/* Render one frame on all devices; the result (row-major H*W*3 reals of opts->real_mode
+ * and/or H*W*3 bytes, either may be NULL) is resident on the FIRST device when the call
+ * returns (blocking).  opts->rank / n_ranks / stream are ignored (the call owns the split). */
+int rtk_render_multi_device(rtk_multi* multi, const rtk_camera* cam, const rtk_render_opts* opts,
+                            void* d_linear, uint8_t* d_rgb8);
+/* The same into host buffers (h_linear: H*W*3 doubles, F32 results widened), as rtk_render_host. */
+int rtk_render_multi(rtk_multi* multi, const rtk_camera* cam, const rtk_render_opts* opts,
+                     double* h_linear, uint8_t* h_rgb8);
+
+/* Progress ----------------------------------------------------------------------
+ * The reference prints "Scanlines remaining" from an atomic the row workers bump
+ * (Camera.txt:63,91,102-106).  Here the render kernel's work-item counter plays
+ * that role: while a blocking render (rtk_render_host, rtk_render_multi*) runs,
+ * the calling thread polls it off the device path -- a host-mapped word the kernel's
+ * existing hand-out atomic is mirrored into; the kernel does no extra work -- and
+ * calls `fn(done, total, user)` with done/total in work items (8x8 tile x sample
+ * chunk), at most every `interval_ms` (<= 0: 100 ms).  fn == NULL switches it off.
+ * Never called from another thread. */
+typedef void (*rtk_progress_fn)(int64_t done, int64_t total, void* user);
+int rtk_set_progress_callback(rtk_ctx* ctx, rtk_progress_fn fn, void* user, int interval_ms);
 
 /* Known-answer / diagnostic entry point: hittable::hit(r, interval(tmin, tmax), rec) of the uploaded
  * scene's root (hittable.h:33) for n caller-supplied rays, run through the same device traversal and

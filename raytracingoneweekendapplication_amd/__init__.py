@@ -82,6 +82,9 @@ class OptimizeInfo(C.Structure):
                 ("expected_cost", C.c_double), ("box_margin", C.c_double)]
 
 
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_int64, C.c_int64, C.c_void_p)  # rtk_progress_fn
+GATHER_AUTO, GATHER_PEER, GATHER_RCCL = 0, 1, 2                     # rtk_gather_mode
+
 COUNTER_FIELDS = (
     "samples", "segments", "box_tests", "sphere_tests", "quad_tests", "triangle_tests",
     "xform_enters", "medium_tests", "surface_hits", "noise_calls", "texel_fetches", "rng_draws",
@@ -95,17 +98,18 @@ class WorkCounters(C.Structure):
         return {name: int(getattr(self, name)) for name in COUNTER_FIELDS}
 
 
-def algorithmic_bytes_per_sample(counters: dict, spp: int, real_mode: int) -> float:
+def algorithmic_bytes_per_sample(counters: dict, spp: int, real_mode: int, f32_boxes: bool = False) -> float:
     """SURVEY.md 8(d) byte model: bytes the sample loop must touch per sample.
 
     fp32 record sizes: BVH node 32, sphere 32, quad 68, triangle 76, instance
     transform 24, medium 12, material 32, perlin::noise 120, texel 4, framebuffer
     12 B/pixel.  In f64 mode the real-valued fields double (the 4-byte indices and
-    the u8 texel do not).
+    the u8 texel do not).  ``f32_boxes``: the launched kernel reads the MIXED program's
+    32-byte f32 culling-box records (F_F32_BOX) whatever the arithmetic type of the primitives.
     """
     n = max(1, counters["samples"])
     f64 = real_mode == RTK_REAL_F64
-    node = 56 if f64 else 32        # 6 reals + 2 u32
+    node = 56 if (f64 and not f32_boxes) else 32        # 6 reals + 2 u32
     sphere = 60 if f64 else 32      # 7 reals + material
     quad = 132 if f64 else 68       # 16 reals + material
     tri = 124 if f64 else 76        # 12 reals + 6 float uv + material
@@ -143,6 +147,8 @@ def host_lib() -> C.CDLL:
         lib.rtkh_scene_rng_draws.restype = C.c_uint64
         lib.rtkh_scene_rng_draws.argtypes = [C.c_void_p]
         lib.rtkh_scene_camera.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Camera)]
+        lib.rtkh_camera_derive.argtypes = [C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                           C.POINTER(C.c_double), C.c_double, C.c_double, C.POINTER(Camera)]
         lib.rtkh_image_texels.restype = C.c_int64
         lib.rtkh_image_texels.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_int64]
         _host_lib = lib
@@ -174,6 +180,18 @@ def hip_lib() -> C.CDLL:
         lib.rtk_scene_optimized_free.argtypes = [C.c_void_p]
         lib.rtk_kernel_name.restype = C.c_char_p
         lib.rtk_kernel_name.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.rtk_scene_upload_optimized.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OptimizeOpts)]
+        lib.rtk_init_multi.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+        lib.rtk_multi_destroy.argtypes = [C.c_void_p]
+        lib.rtk_multi_device_count.argtypes = [C.c_void_p]
+        lib.rtk_multi_uses_rccl.argtypes = [C.c_void_p]
+        lib.rtk_multi_ctx.restype = C.c_void_p
+        lib.rtk_multi_ctx.argtypes = [C.c_void_p, C.c_int]
+        lib.rtk_multi_scene_upload.argtypes = [C.c_void_p, C.c_void_p]
+        lib.rtk_multi_scene_upload_fast.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OptimizeOpts), C.POINTER(OptimizeInfo)]
+        lib.rtk_render_multi_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p, C.c_void_p]
+        lib.rtk_render_multi.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p, C.c_void_p]
+        lib.rtk_set_progress_callback.argtypes = [C.c_void_p, PROGRESS_FN, C.c_void_p, C.c_int]
         if lib.rtk_abi_version() != RTK_ABI_VERSION:
             raise RuntimeError("librtk_hip.so ABI version mismatch")
         _hip_lib = lib
@@ -272,6 +290,17 @@ class FastOrderScene:
             self.close()
         except Exception:
             pass
+
+
+def derive_camera(image_width: int, aspect_ratio: float, *, spp: int = 10, max_depth: int = 10, vfov: float = 90.0, lookfrom=(0.0, 0.0, 0.0),
+                  lookat=(0.0, 0.0, -1.0), vup=(0.0, 1.0, 0.0), defocus_angle: float = 0.0, focus_dist: float = 10.0) -> Camera:
+    """camera::derive() of the drop-in camera (host/rtk_camera.h = camera::initialize, Camera.txt:136-175) for raw public fields."""
+    cam = Camera()
+    v3 = lambda v: (C.c_double * 3)(*v)  # noqa: E731
+    rc = host_lib().rtkh_camera_derive(image_width, aspect_ratio, spp, max_depth, vfov, v3(lookfrom), v3(lookat), v3(vup), defocus_angle, focus_dist, C.byref(cam))
+    if rc != 0:
+        raise ValueError("rtkh_camera_derive failed")
+    return cam
 
 
 def load_image_texels(path: str):
@@ -377,10 +406,80 @@ class Renderer:
         self._check(self._lib.rtk_debug_closest_hit(self._ctx, real_mode, n, rays.ctypes.data, keys.ctypes.data, out.ctypes.data, draws.ctypes.data))
         return out, draws
 
+    def set_progress(self, fn=None, interval_ms: int = 100) -> None:
+        """rtk_set_progress_callback: ``fn(done, total)`` is called from the thread that runs a blocking render
+        (render_host), at most every ``interval_ms``; None switches it off."""
+        self._progress = PROGRESS_FN(lambda done, total, _user: fn(done, total)) if fn else C.cast(None, PROGRESS_FN)
+        self._check(self._lib.rtk_set_progress_callback(self._ctx, self._progress, None, interval_ms))
+
     def close(self) -> None:
         if getattr(self, "_ctx", None):
             self._lib.rtk_destroy(self._ctx)
             self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiRenderer:
+    """rtk_multi: several GPUs of one node behind one call (one host thread, replicated scene, interleaved tiles, one
+    gather to the first device).  ``devices`` are HIP ordinals; an ordinal may repeat (ranks then share a GPU)."""
+
+    def __init__(self, devices, gather: int = GATHER_AUTO):
+        self._lib = hip_lib()
+        devs = (C.c_int * len(devices))(*devices)
+        handle = C.c_void_p()
+        self._check(self._lib.rtk_init_multi(len(devices), devs, gather, C.byref(handle)))
+        self._m = handle
+        self.devices = list(devices)
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise RtkError(rc, self._lib.rtk_last_error().decode())
+
+    @property
+    def uses_rccl(self) -> bool:
+        return bool(self._lib.rtk_multi_uses_rccl(self._m))
+
+    def upload(self, scene) -> None:
+        self._check(self._lib.rtk_multi_scene_upload(self._m, scene.desc_ptr))
+
+    def upload_fast(self, scene, eye: Optional[Vec3] = None) -> dict:
+        opts = OptimizeOpts(1 if eye is not None else 0, 0, eye if eye is not None else Vec3(0, 0, 0), 0.0)
+        info = OptimizeInfo()
+        self._check(self._lib.rtk_multi_scene_upload_fast(self._m, scene.desc_ptr, C.byref(opts), C.byref(info)))
+        return {"exact": bool(info.exact), "has_media": bool(info.has_media), "has_triangles": bool(info.has_triangles)}
+
+    def kernel_name(self, real_mode: int = RTK_REAL_F64, variant: int = 0) -> str:
+        return self._lib.rtk_kernel_name(self._lib.rtk_multi_ctx(self._m, 0), real_mode, variant).decode()
+
+    def set_progress(self, fn=None, interval_ms: int = 100) -> None:
+        self._progress = PROGRESS_FN(lambda done, total, _user: fn(done, total)) if fn else C.cast(None, PROGRESS_FN)
+        self._check(self._lib.rtk_set_progress_callback(self._lib.rtk_multi_ctx(self._m, 0), self._progress, None, interval_ms))
+
+    def render_host(self, cam: Camera, *, seed: int = RENDER_SEED, real_mode: int = RTK_REAL_F64, variant: int = 0):
+        """rtk_render_multi: (linear float64 HxWx3, rgb8 HxWx3)."""
+        import numpy as np
+
+        h, w = cam.image_height, cam.image_width
+        linear = np.zeros((h, w, 3), np.float64)
+        rgb8 = np.zeros((h, w, 3), np.uint8)
+        opts = RenderOpts(seed, real_mode, 0, 1, 0, variant, None)
+        self._check(self._lib.rtk_render_multi(self._m, C.byref(cam), C.byref(opts), linear.ctypes.data, rgb8.ctypes.data))
+        return linear, rgb8
+
+    def render_device(self, cam: Camera, d_linear: int, d_rgb8: int = 0, *, seed: int = RENDER_SEED, real_mode: int = RTK_REAL_F64, variant: int = 0) -> None:
+        """rtk_render_multi_device: blocking; the image is resident on devices[0] on return."""
+        opts = RenderOpts(seed, real_mode, 0, 1, 0, variant, None)
+        self._check(self._lib.rtk_render_multi_device(self._m, C.byref(cam), C.byref(opts), d_linear or None, d_rgb8 or None))
+
+    def close(self) -> None:
+        if getattr(self, "_m", None):
+            self._lib.rtk_multi_destroy(self._m)
+            self._m = None
 
     def __del__(self):
         try:

@@ -7,20 +7,24 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rtk.h"
 #include "rtk_device_layout.h"
+#include "rtk_internal.h"
 #include "rtk_trace.h"
 
-namespace {
+namespace rtk {
 
 thread_local std::string g_error;
 
@@ -33,6 +37,13 @@ int fail(int code, const char* fmt, ...) {
     g_error = buf;
     return code;
 }
+
+}  // namespace rtk
+
+namespace {
+
+using rtk::fail;
+using rtk::g_error;
 
 #define RTK_HIP(call)                                                                              \
     do {                                                                                           \
@@ -619,10 +630,95 @@ struct rtk_ctx {
     bool cam_valid[2] = {false, false};
     rtk_camera cam_last[2];
     unsigned int cam_slot[2] = {0, 0};
+    // Progress reporting (rtk_set_progress_callback): the work-item counter of the last launch and how many items it
+    // hands out; a blocking render polls the counter with a 4-byte device-to-host copy on a stream of its own.
+    rtk_progress_fn progress_fn = nullptr;
+    void* progress_user = nullptr;
+    int progress_interval_ms = 100;
+    const unsigned int* last_tile_counter = nullptr;
+    int64_t last_n_items = 0;
+    hipStream_t progress_stream = nullptr;
+    unsigned int* progress_word = nullptr;  // pinned host memory
+    bool progress_pending = false;
 };
 constexpr unsigned int kCounterRing = 256;
 constexpr size_t kCameraStride = 256;
 static_assert(sizeof(CameraRec<double>) <= kCameraStride, "camera stride");
+
+namespace rtk {
+
+int ctx_device(const rtk_ctx* ctx) { return ctx->device; }
+
+// Block until every stream[i] (a stream of ctxs[i]'s device) has drained.  When ctxs[0] has a progress callback, the
+// work-item counters of the launches in flight are sampled meanwhile -- a 4-byte device-to-host copy per context on a
+// stream of its own (the copy engine, not a CU; the persistent kernel is not touched) -- and the callback gets the sums.
+// A sample that has not landed by the next tick is simply skipped, so a copy stuck behind the kernel can only mean
+// fewer reports, never a stall.
+int wait_with_progress(rtk_ctx* const* ctxs, const hipStream_t* streams, int n) {
+    rtk_ctx* reporter = n > 0 ? ctxs[0] : nullptr;
+    if (!reporter || !reporter->progress_fn) {
+        for (int i = 0; i < n; i++) {
+            hipError_t e = hipSetDevice(ctxs[i]->device);
+            if (e == hipSuccess) e = hipStreamSynchronize(streams[i]);
+            if (e != hipSuccess) return fail(RTK_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
+        }
+        return RTK_OK;
+    }
+    int64_t total = 0;
+    std::vector<int64_t> seen(size_t(n), 0);
+    for (int i = 0; i < n; i++) {
+        rtk_ctx* c = ctxs[i];
+        total += c->last_n_items;
+        if (!c->progress_stream) {
+            (void)hipSetDevice(c->device);
+            if (hipStreamCreateWithFlags(&c->progress_stream, hipStreamNonBlocking) != hipSuccess) c->progress_stream = nullptr;
+            if (hipHostMalloc(reinterpret_cast<void**>(&c->progress_word), sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) c->progress_word = nullptr;
+        }
+        c->progress_pending = false;
+    }
+    const auto tick = std::chrono::milliseconds(reporter->progress_interval_ms);
+    auto next_report = std::chrono::steady_clock::now();
+    for (;;) {
+        bool all_done = true;
+        for (int i = 0; i < n; i++) {
+            (void)hipSetDevice(ctxs[i]->device);
+            const hipError_t q = hipStreamQuery(streams[i]);
+            if (q == hipErrorNotReady) all_done = false;
+            else if (q != hipSuccess) return fail(RTK_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+        }
+        if (all_done) break;
+        if (std::chrono::steady_clock::now() >= next_report) {
+            int64_t done = 0;
+            for (int i = 0; i < n; i++) {
+                rtk_ctx* c = ctxs[i];
+                if (c->progress_stream && c->progress_word && c->last_tile_counter) {
+                    (void)hipSetDevice(c->device);
+                    if (c->progress_pending && hipStreamQuery(c->progress_stream) == hipSuccess) {
+                        seen[size_t(i)] = std::min<int64_t>(int64_t(*c->progress_word), c->last_n_items);
+                        c->progress_pending = false;
+                    }
+                    if (!c->progress_pending &&
+                        hipMemcpyAsync(c->progress_word, c->last_tile_counter, sizeof(unsigned int), hipMemcpyDeviceToHost, c->progress_stream) == hipSuccess)
+                        c->progress_pending = true;
+                }
+                done += seen[size_t(i)];
+            }
+            reporter->progress_fn(done, total, reporter->progress_user);
+            next_report = std::chrono::steady_clock::now() + tick;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    for (int i = 0; i < n; i++)
+        if (ctxs[i]->progress_stream) {
+            (void)hipSetDevice(ctxs[i]->device);
+            (void)hipStreamSynchronize(ctxs[i]->progress_stream);
+            ctxs[i]->progress_pending = false;
+        }
+    reporter->progress_fn(total, total, reporter->progress_user);
+    return RTK_OK;
+}
+
+}  // namespace rtk
 
 extern "C" {
 
@@ -668,7 +764,17 @@ int rtk_destroy(rtk_ctx* ctx) {
     if (ctx->d_partial) (void)hipFree(ctx->d_partial);
     if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
     if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
+    if (ctx->progress_stream) (void)hipStreamDestroy(ctx->progress_stream);
+    if (ctx->progress_word) (void)hipHostFree(ctx->progress_word);
     delete ctx;
+    return RTK_OK;
+}
+
+int rtk_set_progress_callback(rtk_ctx* ctx, rtk_progress_fn fn, void* user, int interval_ms) {
+    if (!ctx) return fail(RTK_ERR_INVALID, "rtk_set_progress_callback: null context");
+    ctx->progress_fn = fn;
+    ctx->progress_user = user;
+    ctx->progress_interval_ms = interval_ms > 0 ? interval_ms : 100;
     return RTK_OK;
 }
 
@@ -692,16 +798,42 @@ int rtk_scene_upload_fast(rtk_ctx* ctx, const rtk_scene_desc* scene, const rtk_o
     return rc;
 }
 
-static int upload_scene(rtk_ctx* ctx, const rtk_scene_desc* scene, uint32_t hierarchy_flags, double eye_extent) {
+int rtk_scene_upload_optimized(rtk_ctx* ctx, const rtk_scene_desc* optimized, const rtk_optimize_opts* opts) {
+    if (!ctx || !optimized) return fail(RTK_ERR_INVALID, "rtk_scene_upload_optimized: null argument");
+    double eye_extent = 0.0;
+    if (opts && opts->has_eye) eye_extent = std::max(std::fabs(opts->eye.x), std::max(std::fabs(opts->eye.y), std::fabs(opts->eye.z)));
+    return upload_scene(ctx, optimized, F_FMA_BOX, eye_extent);
+}
+
+// Everything that can be decided without a device: table validation and the compilation of the traversal program.
+static int compile_scene(const rtk_scene_desc* scene, Program& prog) {
     int rc = validate_tables(*scene);
     if (rc != RTK_OK) return rc;
-    Program prog;
     Compiler comp{*scene, prog};
     comp.chain_id(Chain{});  // chain 0 = world space
     comp.emit(scene->root, Chain{}, false, 0);
     if (prog.error_code != RTK_OK) return fail(prog.error_code, "rtk_scene_upload: %s", prog.error.c_str());
     if (prog.n_primitive_ops == 0) return fail(RTK_ERR_INVALID, "rtk_scene_upload: no primitive reachable from the root");
     prog.ops.push_back(Op{make_op(OP_END, 0), 0});
+    return RTK_OK;
+}
+
+int rtk_scene_validate(const rtk_scene_desc* scene, int32_t* n_program_ops) {
+    if (!scene) return fail(RTK_ERR_INVALID, "rtk_scene_validate: null argument");
+    try {
+        Program prog;
+        const int rc = compile_scene(scene, prog);
+        if (rc == RTK_OK && n_program_ops) *n_program_ops = int32_t(prog.ops.size());
+        return rc;
+    } catch (const std::bad_alloc&) {
+        return fail(RTK_ERR_UNSUPPORTED, "rtk_scene_validate: out of memory while compiling the traversal program");
+    }
+}
+
+static int upload_scene(rtk_ctx* ctx, const rtk_scene_desc* scene, uint32_t hierarchy_flags, double eye_extent) {
+    Program prog;
+    int rc = compile_scene(scene, prog);
+    if (rc != RTK_OK) return rc;
     for (int32_t i = 0; i < scene->n_materials; i++) {
         const rtk_material& m = scene->materials[i];
         if (m.kind == RTK_MAT_DIFFUSE_LIGHT || m.kind == RTK_MAT_ISOTROPIC || m.kind == RTK_MAT_SPECULAR) prog.features |= F_EXOTIC_MAT;
@@ -806,6 +938,8 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
     unsigned int* tile_cost = learn ? ctx->d_tile_cost : nullptr;
     const unsigned int slot = ctx->next_counter++ % kCounterRing;
     unsigned int* tile_counter = ctx->tile_counters + slot;
+    ctx->last_tile_counter = tile_counter;
+    ctx->last_n_items = int64_t(tm.n_tiles_local) * tm.n_chunks;
     const int cam_mode = opts->real_mode == RTK_REAL_F64 ? 0 : 1;
     const bool cam_cached = ctx->cam_valid[cam_mode] && std::memcmp(&ctx->cam_last[cam_mode], cam, sizeof(rtk_camera)) == 0;
     const unsigned int cslot = cam_cached ? ctx->cam_slot[cam_mode] : (ctx->next_camera++ % kCounterRing);
@@ -895,7 +1029,14 @@ int rtk_render_host(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts* 
         cleanup();
         return rc;
     }
-    RTK_HIP_CLEAN(hipStreamSynchronize(static_cast<hipStream_t>(o.stream)));
+    {
+        hipStream_t st = static_cast<hipStream_t>(o.stream);
+        rc = rtk::wait_with_progress(&ctx, &st, 1);
+        if (rc != RTK_OK) {
+            cleanup();
+            return rc;
+        }
+    }
     if (h_linear) {
         if (opts->real_mode == RTK_REAL_F64) {
             RTK_HIP_CLEAN(hipMemcpy(h_linear, d_linear, n * sizeof(double), hipMemcpyDeviceToHost));

@@ -314,6 +314,16 @@ struct Optimizer {
             failed = true;
             return -1;
         }
+        // Geometry the surface-area heuristic cannot price (a NaN, an infinity or a coordinate beyond 1e150 -- areas
+        // overflow -- from a damaged description) is refused rather than sorted: RTK_ERR_INVALID.
+        for (int a = 0; a < 3; a++) {
+            const bool empty_axis = !(box.lo[a] <= box.hi[a]);
+            const bool nan_axis = box.lo[a] != box.lo[a] || box.hi[a] != box.hi[a];
+            if (nan_axis || (!empty_axis && (std::fabs(box.lo[a]) > 1e150 || std::fabs(box.hi[a]) > 1e150)) || !(cost == cost) || cost > 1e300) {
+                failed = true;
+                return -1;
+            }
+        }
         memo[node] = o;
         memo_box[node] = box;
         memo_cost[node] = cost;
@@ -424,6 +434,10 @@ struct Optimizer {
         // Degenerate inputs (thousands of coincident boxes) can make the heuristic peel off one item per level; past a
         // depth no sane hierarchy needs, split at the median instead so that recursion depth and work stay bounded.
         if (split_depth > 48 && (best_k == 1 || best_k + 1 == n)) best_k = n / 2;
+        if (best_axis < 0) {  // no finite cost at all (cannot happen for the finite boxes convert() lets through): median of the last sort
+            best_axis = 2;
+            best_k = n / 2;
+        }
         if (best_axis != 2)
             std::sort(items.begin() + long(begin), items.begin() + long(end), [&](const Item& x, const Item& y) {
                 const double cx = x.box.centre(best_axis), cy = y.box.centre(best_axis);

@@ -10,7 +10,8 @@ namespace rtk {
 
 // Enqueue the render kernel for one rank's tiles.  `features` selects the
 // kernel instantiation (kFeatLean or kFeatAll); `count` selects the
-// work-counting instantiation (always the full-feature kernel).  tile_counter is
+// work-counting instantiation (the full-feature kernel, or -- for a scene with a
+// MIXED program -- the counting build of the F_F32_BOX kernel itself).  tile_counter is
 // a device word the persistent waves pull tile indices from (zeroed on `stream`
 // before the launch); d_cam points at the camera record in device memory.  `diag`
 // bits 8..13 select scheduler thresholds for A/B runs from tools/ (images are unaffected).

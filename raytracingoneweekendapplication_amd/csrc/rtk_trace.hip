@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
     constexpr bool SPLIT = (FEAT_ALL & F_LDS_BOXES) != 0;  // boxes, kinds and the rank table in LDS; everything else of the program in HBM/L2
     static_assert(!SPLIT || (!IN_LDS && (FEAT & F_F32_BOX) == 0), "F_LDS_BOXES: for programs that do not fit LDS");
     constexpr bool MIXED = (FEAT & F_F32_BOX) != 0;  // the MIXED program: f32 culling boxes, 32-byte units (f64, sphere-only scenes)
-    static_assert(!MIXED || (sizeof(real) == 8 && (FEAT & ~uint32_t(F_F32_BOX)) == kFeatLean && !COUNT), "F_F32_BOX: lean f64 kernels only");
+    static_assert(!MIXED || (sizeof(real) == 8 && (FEAT & ~uint32_t(F_F32_BOX)) == kFeatLean), "F_F32_BOX: lean f64 kernels only");
     using ProgRec = std::conditional_t<MIXED, MixedHead, Slot<real>>;
     const ProgRec* prog;
     if constexpr (MIXED) prog = sc.program_mixed;
@@ -1797,7 +1797,9 @@ static bool use_mixed_program(const SceneView<real>& sc, uint32_t diag) {
 // `mixed` = the scene has a MIXED program (f64, sphere-only, fast order) and the caller did not ask for the f64 boxes.
 static uint32_t kernel_features(uint32_t features, bool count, bool mixed) {
     const uint32_t fma = features & F_FMA_BOX, matte = features & F_MATTE, scene = features & ~uint32_t(F_FMA_BOX | F_MATTE);
-    if (count) return kFeatAll | fma;
+    // counting instantiations: the MIXED program has its own (the kernel bench.py times on sphere-only scenes, with
+    // counters); everything else counts with the full-feature kernel
+    if (count) return (mixed && scene == kFeatLean) ? (kFeatLean | uint32_t(F_F32_BOX)) : (kFeatAll | fma);
     if (scene == kFeatLean) return mixed ? (kFeatLean | uint32_t(F_F32_BOX)) : (kFeatLean | fma);
     if ((scene & ~kFeatQuadBox) == 0) return kFeatQuadBox | matte;  // no registers to spare for o*inv at 4 waves/SIMD (it spills): exact slab test, A/B on C3 40.7 vs 42.2 ms
     if ((scene & ~kFeatMesh) == 0) return kFeatMesh | fma | matte;
@@ -1810,6 +1812,11 @@ static hipError_t launch_feat(const SceneView<real>& sc, const CameraRec<real>* 
                               hipStream_t stream) {
     if constexpr ((FEAT & ~uint32_t(F_FMA_BOX)) == kFeatAll) {
         if (count) return launch_one<real, FEAT, true, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
+    }
+    if constexpr ((FEAT & F_F32_BOX) != 0) {  // the timed sphere-scene kernel with work counters: same program, same steps, same LDS staging
+        if (count)
+            return lds ? launch_one<real, FEAT, true, true>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream)
+                       : launch_one<real, FEAT, true, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
     }
     if constexpr ((FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatMesh || (FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatAll) {
         if (use_lds_boxes(sc, FEAT, lds, count, diag))
@@ -1895,7 +1902,8 @@ const char* render_kernel_name(bool f64, uint32_t features, bool count, bool lds
     uint32_t feat = kernel_features(f64 ? features : (features & ~uint32_t(F_MATTE)), count, mixed && f64);
     const uint32_t scene = feat & ~uint32_t(F_FMA_BOX | F_MATTE);
     if (!lds && !count && has_box_cache && (scene == kFeatMesh || scene == kFeatAll) && (diag & (1u << 21)) == 0) feat |= uint32_t(F_LDS_BOXES);
-    snprintf(name, sizeof name, "rtk_render_kernel<%s, %uu, %s, %s>", f64 ? "double" : "float", feat, count ? "true" : "false", (lds && !count) ? "true" : "false");
+    const bool counting_in_lds = (feat & F_F32_BOX) != 0;  // the only counting instantiation that stages its program
+    snprintf(name, sizeof name, "rtk_render_kernel<%s, %uu, %s, %s>", f64 ? "double" : "float", feat, count ? "true" : "false", (lds && (!count || counting_in_lds)) ? "true" : "false");
     return name;
 }
 

@@ -107,7 +107,16 @@ public:
     uint32_t seed = 1;                 // render seed: per-sample RNG streams are f(seed, pixel, sample)
     int real_mode = RTK_REAL_F64;      // the reference computes in double
     int device = 0;                    // HIP device ordinal
+    // More than one entry: render() splits the image over these HIP devices (interleaved 8x8 tiles, replicated scene,
+    // one gather to devices[0] -- rtk_render_multi); render() owns the whole parallel split, as the reference's does
+    // (Camera.txt:59-61,96-100).  The image does not depend on the list.  Empty or one entry: `device` / that entry.
+    std::vector<int> devices;
     bool write_image = true;           // write image_name as PNG after rendering
+    // Progress: the reference prints "Percent Rendered: N%" every 100 ms while its row workers run (Camera.txt:102-106).
+    // show_progress does the same from the render kernel's work-item counter; `progress` (if set) is called instead.
+    bool show_progress = true;
+    rtk_progress_fn progress = nullptr;
+    void* progress_user = nullptr;
     // Visiting order of the hierarchy.  auto_order (default): the fast order of rtk_scene_upload_fast (same primitives, SAH
     // grouping, ~half the aabb::hit calls) whenever it is provably bit-identical to the reference's bvh_node order -- no
     // constant_medium, no triangle -- and the reference order otherwise, so the image never depends on this choice.
@@ -165,8 +174,10 @@ public:
         rtk::scene_builder sb;
         rtk_scene_desc desc = rtk::flatten(world, lights, sb);
         rtk_camera cam = derive();
-        rtk_ctx* ctx = nullptr;
-        int rc = rtk_init(device, &ctx);
+        std::vector<int> devs = devices.empty() ? std::vector<int>{device} : devices;
+        if (counters && devs.size() > 1) devs.resize(1);  // work counters are per device: a counting render uses the first one
+        rtk_multi* multi = nullptr;
+        int rc = rtk_init_multi(int(devs.size()), devs.data(), RTK_GATHER_AUTO, &multi);
         if (rc != RTK_OK) return rc;
         used_fast_order = false;
         fast_order_exact = false;
@@ -175,11 +186,13 @@ public:
             oo.has_eye = 1;
             oo.eye = cam.center;
             rtk_optimize_info info{};
-            rc = rtk_scene_upload_fast(ctx, &desc, &oo, &info);
+            rc = rtk_multi_scene_upload_fast(multi, &desc, &oo, &info);
             fast_order_exact = rc == RTK_OK && info.exact != 0;
             used_fast_order = rc == RTK_OK && (order == fast_order || fast_order_exact);
+            // auto_order never makes render() fail on a scene the reference order accepts: fall back to it
+            if (rc != RTK_OK && order == auto_order) rc = RTK_OK;
         }
-        if (rc == RTK_OK && !used_fast_order) rc = rtk_scene_upload(ctx, &desc);  // the reference's own hierarchy and order
+        if (rc == RTK_OK && !used_fast_order) rc = rtk_multi_scene_upload(multi, &desc);  // the reference's own hierarchy and order
         if (rc == RTK_OK) {
             size_t n = size_t(cam.image_width) * cam.image_height * 3;
             if (linear) linear->assign(n, 0.0);
@@ -190,12 +203,21 @@ public:
             opts.rank = 0;
             opts.n_ranks = 1;
             opts.count_work = counters ? 1 : 0;
+            if (progress) rtk_set_progress_callback(rtk_multi_ctx(multi, 0), progress, progress_user, 100);
+            else if (show_progress) rtk_set_progress_callback(rtk_multi_ctx(multi, 0), &camera::print_progress, nullptr, 100);
             auto t0 = std::chrono::steady_clock::now();
-            rc = rtk_render_host(ctx, &cam, &opts, linear ? linear->data() : nullptr, rgb8 ? rgb8->data() : nullptr, counters);
+            if (counters) rc = rtk_render_host(rtk_multi_ctx(multi, 0), &cam, &opts, linear ? linear->data() : nullptr, rgb8 ? rgb8->data() : nullptr, counters);
+            else rc = rtk_render_multi(multi, &cam, &opts, linear ? linear->data() : nullptr, rgb8 ? rgb8->data() : nullptr);
             last_render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
-        rtk_destroy(ctx);
+        rtk_multi_destroy(multi);
         return rc;
+    }
+
+    // Camera.txt:102-106: "\rPercent Rendered: N% " on stderr.
+    static void print_progress(int64_t done, int64_t total, void*) {
+        const float percent = total > 0 ? 100.0f * float(done) / float(total) : 100.0f;
+        std::cerr << "\rPercent Rendered: " << static_cast<int>(percent) << "% " << std::flush;
     }
 
     // Camera.txt:54.  Blocking; borrows world and lights for the call.

@@ -77,9 +77,27 @@ struct desc_storage {
         int64_t ntex = 0;
         bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "RTKSCN1", 8) == 0 && std::fread(head, sizeof(int32_t), 16, f) == 16 &&
                   std::fread(&ntex, sizeof(int64_t), 1, f) == 1;
+        // a count is believed only if the rest of the file can hold that many records (a negative or absurd count in a
+        // damaged file must not size an allocation)
+        int64_t remaining = 0;
+        if (ok) {
+            const long here = std::ftell(f);
+            if (here < 0 || std::fseek(f, 0, SEEK_END) != 0) ok = false;
+            const long size = ok ? std::ftell(f) : -1;
+            if (size < here || std::fseek(f, here, SEEK_SET) != 0) ok = false;
+            remaining = ok ? int64_t(size - here) : 0;
+        }
         auto get = [&](auto& vec, int64_t n) {
+            vec.clear();
+            if (!ok) return;
+            const int64_t bytes_each = int64_t(sizeof(vec[0]));
+            if (n < 0 || n > remaining / bytes_each) {
+                ok = false;
+                return;
+            }
             vec.resize(size_t(n));
-            if (ok && n > 0) ok = std::fread(vec.data(), sizeof(vec[0]), size_t(n), f) == size_t(n);
+            if (n > 0) ok = std::fread(vec.data(), sizeof(vec[0]), size_t(n), f) == size_t(n);
+            remaining -= n * bytes_each;
         };
         if (ok) {
             get(nodes, head[1]); get(list_children, head[2]); get(spheres, head[3]); get(quads, head[4]);

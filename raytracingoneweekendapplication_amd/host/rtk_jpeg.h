@@ -216,6 +216,10 @@ private:
         img_w = (p[3] << 8) | p[4];
         n_comp = p[5];
         if (img_w <= 0 || img_h <= 0 || (n_comp != 1 && n_comp != 3) || len < 8 + 3 * n_comp) return false;
+        // The planes below are sized from these 16-bit fields: believe them only if the file could hold such an image.
+        // Every 8x8 block costs at least two bits of entropy-coded data (a DC code and an end-of-block code), i.e. at
+        // most 256 pixels per byte of file; and nothing above 2^27 pixels is decoded at all.
+        if (uint64_t(img_w) * uint64_t(img_h) > (uint64_t(1) << 27) || uint64_t(img_w) * uint64_t(img_h) > uint64_t(end - src) * 256 + 4096) return false;
         h_max = v_max = 1;
         for (int c = 0; c < n_comp; c++) {
             comp[c].id = p[6 + 3 * c];
@@ -329,9 +333,9 @@ private:
         int s = decode_symbol(dc);
         if (s < 0 || s > 15) return false;
         int diff = s ? extend(get_bits(s), s) : 0;
-        c.dc_pred += diff;
+        c.dc_pred = int(uint32_t(c.dc_pred) + uint32_t(diff));  // wrapping: a damaged stream must not overflow a signed int
         const uint16_t* q = quant[c.tq];
-        coef[0] = int16_t(c.dc_pred * q[0]);
+        coef[0] = int16_t(uint32_t(c.dc_pred) * uint32_t(q[0]));
         for (int k = 1; k < 64;) {
             int rs = decode_symbol(ac);
             if (rs < 0) return false;
@@ -352,21 +356,25 @@ private:
 
     // 8-point inverse DCT, Loeffler-Ligtenberg-Moschytz factorisation, 12-bit fixed-point constants.  `shifted`
     // inputs: even part scaled by 4096; returns the eight butterfly outputs (before the final pairing) in e[] / o[].
-    static void idct_1d(const int32_t s[8], int32_t e[4], int32_t o[4]) {
-        constexpr int32_t c0_541 = 2217, c1_847 = -7567, c0_765 = 3135, c1_175 = 4816, c0_298 = 1223, c2_053 = 8410, c3_072 = 12586,
-                          c1_501 = 6149, c0_899 = -3685, c2_562 = -10497, c1_961 = -8034, c0_390 = -1597;
+    // All IDCT arithmetic is done in uint32_t: the same bits as stb_image's int arithmetic on every decodable file, and
+    // defined (wrapping) on a damaged one whose coefficients would overflow a signed int.  sar() is the arithmetic shift.
+    using u32 = uint32_t;
+    static int32_t sar(u32 v, int n) { return int32_t(v) >> n; }
+    static void idct_1d(const u32 s[8], u32 e[4], u32 o[4]) {
+        constexpr u32 c0_541 = 2217, c1_847 = u32(-7567), c0_765 = 3135, c1_175 = 4816, c0_298 = 1223, c2_053 = 8410, c3_072 = 12586,
+                      c1_501 = 6149, c0_899 = u32(-3685), c2_562 = u32(-10497), c1_961 = u32(-8034), c0_390 = u32(-1597);
         // even part
-        int32_t z = (s[2] + s[6]) * c0_541;
-        int32_t t2 = z + s[6] * c1_847, t3 = z + s[2] * c0_765;
-        int32_t t0 = (s[0] + s[4]) * 4096, t1 = (s[0] - s[4]) * 4096;
+        u32 z = (s[2] + s[6]) * c0_541;
+        u32 t2 = z + s[6] * c1_847, t3 = z + s[2] * c0_765;
+        u32 t0 = (s[0] + s[4]) * 4096u, t1 = (s[0] - s[4]) * 4096u;
         e[0] = t0 + t3;
         e[3] = t0 - t3;
         e[1] = t1 + t2;
         e[2] = t1 - t2;
         // odd part
-        int32_t a0 = s[7], a1 = s[5], a2 = s[3], a3 = s[1];
-        int32_t p3 = a0 + a2, p4 = a1 + a3, p1 = a0 + a3, p2 = a1 + a2;
-        int32_t p5 = (p3 + p4) * c1_175;
+        u32 a0 = s[7], a1 = s[5], a2 = s[3], a3 = s[1];
+        u32 p3 = a0 + a2, p4 = a1 + a3, p1 = a0 + a3, p2 = a1 + a2;
+        u32 p5 = (p3 + p4) * c1_175;
         a0 *= c0_298;
         a1 *= c2_053;
         a2 *= c3_072;
@@ -383,34 +391,34 @@ private:
     static uint8_t clamp8(int32_t v) { return uint8_t(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
     static void idct_block(const int16_t coef[64], uint8_t* out, int stride) {
-        int32_t tmp[64];
+        u32 tmp[64];
         for (int x = 0; x < 8; x++) {  // columns: keep two fractional bits
-            int32_t s[8], e[4], o[4];
-            for (int k = 0; k < 8; k++) s[k] = coef[x + 8 * k];
+            u32 s[8], e[4], o[4];
+            for (int k = 0; k < 8; k++) s[k] = u32(int32_t(coef[x + 8 * k]));
             idct_1d(s, e, o);
-            for (int k = 0; k < 4; k++) e[k] += 512;
-            tmp[x + 0] = (e[0] + o[3]) >> 10;
-            tmp[x + 56] = (e[0] - o[3]) >> 10;
-            tmp[x + 8] = (e[1] + o[2]) >> 10;
-            tmp[x + 48] = (e[1] - o[2]) >> 10;
-            tmp[x + 16] = (e[2] + o[1]) >> 10;
-            tmp[x + 40] = (e[2] - o[1]) >> 10;
-            tmp[x + 24] = (e[3] + o[0]) >> 10;
-            tmp[x + 32] = (e[3] - o[0]) >> 10;
+            for (int k = 0; k < 4; k++) e[k] += 512u;
+            tmp[x + 0] = u32(sar(e[0] + o[3], 10));
+            tmp[x + 56] = u32(sar(e[0] - o[3], 10));
+            tmp[x + 8] = u32(sar(e[1] + o[2], 10));
+            tmp[x + 48] = u32(sar(e[1] - o[2], 10));
+            tmp[x + 16] = u32(sar(e[2] + o[1], 10));
+            tmp[x + 40] = u32(sar(e[2] - o[1], 10));
+            tmp[x + 24] = u32(sar(e[3] + o[0], 10));
+            tmp[x + 32] = u32(sar(e[3] - o[0], 10));
         }
         for (int y = 0; y < 8; y++) {  // rows: round at 17 bits, +128 level shift folded in
-            int32_t e[4], o[4];
+            u32 e[4], o[4];
             idct_1d(tmp + 8 * y, e, o);
-            for (int k = 0; k < 4; k++) e[k] += 65536 + (128 << 17);
+            for (int k = 0; k < 4; k++) e[k] += 65536u + (128u << 17);
             uint8_t* row = out + y * stride;
-            row[0] = clamp8((e[0] + o[3]) >> 17);
-            row[7] = clamp8((e[0] - o[3]) >> 17);
-            row[1] = clamp8((e[1] + o[2]) >> 17);
-            row[6] = clamp8((e[1] - o[2]) >> 17);
-            row[2] = clamp8((e[2] + o[1]) >> 17);
-            row[5] = clamp8((e[2] - o[1]) >> 17);
-            row[3] = clamp8((e[3] + o[0]) >> 17);
-            row[4] = clamp8((e[3] - o[0]) >> 17);
+            row[0] = clamp8(sar(e[0] + o[3], 17));
+            row[7] = clamp8(sar(e[0] - o[3], 17));
+            row[1] = clamp8(sar(e[1] + o[2], 17));
+            row[6] = clamp8(sar(e[1] - o[2], 17));
+            row[2] = clamp8(sar(e[2] + o[1], 17));
+            row[5] = clamp8(sar(e[2] - o[1], 17));
+            row[3] = clamp8(sar(e[3] + o[0], 17));
+            row[4] = clamp8(sar(e[3] - o[0], 17));
         }
     }
 
@@ -422,8 +430,8 @@ private:
             int s = decode_symbol(dc);
             if (s < 0 || s > 15) return false;
             int diff = s ? extend(get_bits(s), s) : 0;
-            c.dc_pred += diff;
-            data[0] = int16_t(c.dc_pred * (1 << succ_low));
+            c.dc_pred = int(uint32_t(c.dc_pred) + uint32_t(diff));  // wrapping: a damaged stream must not overflow a signed int
+            data[0] = int16_t(uint32_t(c.dc_pred) << succ_low);
         } else if (get_bits(1)) {
             data[0] = int16_t(data[0] + (1 << succ_low));
         }

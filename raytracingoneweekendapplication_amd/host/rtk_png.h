@@ -71,6 +71,23 @@ public:
         std::vector<uint8_t> raw;
         if (!inflate_zlib(idat, raw)) return false;
 
+        // The header's dimensions are only believed once the inflated data can pay for them: the filtered size of every
+        // pass (one filter byte + the packed row, per row) must be present BEFORE anything is sized from w x h.  (A
+        // 60-byte file may claim 2^24 x 2^24 pixels; deflate expands at most ~1032:1, so `raw` itself is bounded by the file.)
+        if (uint64_t(w) * h > kMaxPixels) return false;
+        {
+            uint64_t need = 0;
+            auto pass_bytes = [&](uint64_t pw, uint64_t ph) { return (pw == 0 || ph == 0) ? 0 : ph * (1 + (pw * uint64_t(channels) * depth + 7) / 8); };
+            if (!interlace) {
+                need = pass_bytes(w, h);
+            } else {
+                static const int ax0[7] = {0, 4, 0, 2, 0, 1, 0}, ay0[7] = {0, 0, 4, 0, 2, 0, 1}, adx[7] = {8, 8, 4, 4, 2, 2, 1}, ady[7] = {8, 8, 8, 4, 4, 2, 2};
+                for (int p = 0; p < 7; p++)
+                    need += pass_bytes(w > uint32_t(ax0[p]) ? (w - ax0[p] + adx[p] - 1) / adx[p] : 0, h > uint32_t(ay0[p]) ? (h - ay0[p] + ady[p] - 1) / ady[p] : 0);
+            }
+            if (uint64_t(raw.size()) < need) return false;
+        }
+
         // samples of the whole image as 8-bit channels (palette indices stay indices), then to RGB
         std::vector<uint8_t> samples(size_t(w) * h * channels);
         size_t offset = 0;
@@ -105,6 +122,7 @@ public:
     }
 
 private:
+    static constexpr uint64_t kMaxPixels = uint64_t(1) << 27;  // 134 Mpixel: larger images are refused (stb caps each dimension at 2^24)
     static uint32_t be32(const uint8_t* p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3]; }
     static bool valid_format(int colour, int depth) {
         switch (colour) {

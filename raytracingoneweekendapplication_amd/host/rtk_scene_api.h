@@ -22,6 +22,8 @@
 #include <cstring>
 #include <fstream>
 #include <iterator>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -145,7 +147,20 @@ public:
         im->bytes.assign(rgb, rgb + size_t(w) * h * 3);
         return im;
     }
+    // false when the file cannot be read or decoded -- including when decoding it would need more memory than the
+    // machine has: an image that fails to load renders cyan (texture.h:92), it never takes the program down.
     bool load(const std::string& path) {
+        try {
+            return load_or_throw(path);
+        } catch (const std::bad_alloc&) {
+            bytes.clear();
+            return false;
+        } catch (const std::length_error&) {
+            bytes.clear();
+            return false;
+        }
+    }
+    bool load_or_throw(const std::string& path) {
         std::ifstream f(path, std::ios::binary);
         if (!f.good()) return false;
         std::vector<uint8_t> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
@@ -189,9 +204,12 @@ public:
                 continue;
             }
             if (c < '0' || c > '9') return false;
-            int v = 0;
-            while (pos < file.size() && file[pos] >= '0' && file[pos] <= '9') v = v * 10 + (file[pos++] - '0');
-            vals[got++] = v;
+            long long v = 0;
+            while (pos < file.size() && file[pos] >= '0' && file[pos] <= '9') {
+                v = v * 10 + (file[pos++] - '0');
+                if (v > (1 << 24)) return false;  // no dimension (or maxval) is that large
+            }
+            vals[got++] = int(v);
         }
         if (got < 3 || vals[2] != 255 || vals[0] <= 0 || vals[1] <= 0) return false;
         pos++;  // the single whitespace byte after maxval

@@ -93,6 +93,27 @@ int rtkh_scene_camera(const rtkh_scene* s, int width, int height, int spp, int d
     return out->image_height == v.image_height ? 0 : -2;
 }
 
+// camera::derive() (= camera::initialize(), Camera.txt:136-175) for caller-supplied public camera fields: the
+// image_height = int(image_width / aspect_ratio), "< 1 -> 1" rule (Camera.txt:137-138) and the viewport vectors,
+// exactly as camera::render() computes them.  For tests of that rule over arbitrary widths and aspect ratios.
+int rtkh_camera_derive(int image_width, double aspect_ratio, int samples_per_pixel, int max_depth, double vfov, const double* lookfrom,
+                       const double* lookat, const double* vup, double defocus_angle, double focus_dist, rtk_camera* out) {
+    if (!lookfrom || !lookat || !vup || !out) return -1;
+    camera cam;
+    cam.image_width = image_width;
+    cam.aspect_ratio = aspect_ratio;
+    cam.samples_per_pixel = samples_per_pixel;
+    cam.max_depth = max_depth;
+    cam.vfov = vfov;
+    cam.lookfrom = point3(lookfrom[0], lookfrom[1], lookfrom[2]);
+    cam.lookat = point3(lookat[0], lookat[1], lookat[2]);
+    cam.vup = vec3(vup[0], vup[1], vup[2]);
+    cam.defocus_angle = defocus_angle;
+    cam.focus_dist = focus_dist;
+    *out = cam.derive();
+    return 0;
+}
+
 // The texels rtw_image holds for an image file (PPM or baseline JPEG), i.e. what image_texture::value reads
 // (texture.h:90-104).  Returns the byte count (width * height * 3) and fills `out` when it is large enough;
 // -1 when the file cannot be loaded (rtw_stb_image.h:62: width() == 0).

@@ -12,6 +12,19 @@
 
 #include <cstring>
 
+struct progress_log {
+    int calls = 0;
+    bool monotone = true;
+    int64_t last = -1, total = 0;
+};
+static void on_progress(int64_t done, int64_t total, void* user) {
+    auto* log = static_cast<progress_log*>(user);
+    log->calls++;
+    if (done < log->last || done > total) log->monotone = false;
+    log->last = done;
+    log->total = total;
+}
+
 static hittable_list spheres_scene(bool with_fog) {
     hittable_list world;
     world.add(make_shared<sphere>(point3(0, -1000, 0), 1000, make_shared<lambertian>(color(0.5, 0.5, 0.5))));
@@ -56,15 +69,37 @@ int main() {
         const bool auto_used_fast = cam.used_fast_order, exact = cam.fast_order_exact;
         cam.order = camera::fast_order;
         int rc2 = cam.render_to(world, lights, &fast, nullptr);
+        // camera::devices: render() owns the split over several GPUs (here the same GPU listed twice and three times:
+        // two / three ranks, tile buffers, one gather, un-permute) -- the image must be the very same doubles and bytes
+        std::vector<double> two, three;
+        std::vector<uint8_t> bytes1, bytes3;
+        cam.order = camera::reference_order;
+        progress_log log;
+        cam.progress = &on_progress;
+        cam.progress_user = &log;
+        cam.devices = {0, 0};
+        int rc3 = cam.render_to(world, lights, &two, nullptr);
+        cam.devices = {0, 0, 0};
+        cam.order = camera::auto_order;
+        int rc4 = cam.render_to(world, lights, &three, &bytes3);
+        cam.devices.clear();
+        cam.progress = nullptr;
+        int rc5 = cam.render_to(world, lights, nullptr, &bytes1);
+        const bool same_two = ref.size() == two.size() && std::memcmp(ref.data(), two.data(), ref.size() * sizeof(double)) == 0;
+        const bool same_three = ref.size() == three.size() && std::memcmp(ref.data(), three.data(), ref.size() * sizeof(double)) == 0;
+        const bool same_bytes = bytes1.size() == bytes3.size() && !bytes1.empty() && std::memcmp(bytes1.data(), bytes3.data(), bytes1.size()) == 0;
+        ok = ok && rc3 == 0 && rc4 == 0 && rc5 == 0;
         const bool same_auto = ref.size() == aut.size() && std::memcmp(ref.data(), aut.data(), ref.size() * sizeof(double)) == 0;
         const bool same_fast = ref.size() == fast.size() && std::memcmp(ref.data(), fast.data(), ref.size() * sizeof(double)) == 0;
         double mean_ref = 0, mean_fast = 0;
         for (double v : ref) mean_ref += v;
         for (double v : fast) mean_fast += v;
         std::printf("%s\"fog%d\": {\"rc\": [%d, %d, %d], \"exact\": %s, \"auto_used_fast\": %s, \"auto_identical\": %s, \"fast_identical\": %s, "
-                    "\"mean_ref\": %.6f, \"mean_fast\": %.6f}",
+                    "\"mean_ref\": %.6f, \"mean_fast\": %.6f, \"two_devices_identical\": %s, \"three_devices_identical\": %s, \"bytes_identical\": %s, "
+                    "\"progress_calls\": %d, \"progress_monotone\": %s, \"progress_reached_total\": %s}",
                     fog ? ", " : "", fog, rc0, rc1, rc2, exact ? "true" : "false", auto_used_fast ? "true" : "false", same_auto ? "true" : "false",
-                    same_fast ? "true" : "false", mean_ref / ref.size(), mean_fast / fast.size());
+                    same_fast ? "true" : "false", mean_ref / ref.size(), mean_fast / fast.size(), same_two ? "true" : "false", same_three ? "true" : "false",
+                    same_bytes ? "true" : "false", log.calls, log.monotone ? "true" : "false", (log.total > 0 && log.last == log.total) ? "true" : "false");
         ok = ok && rc0 == 0 && rc1 == 0 && rc2 == 0;
     }
     std::printf("}\n");

@@ -43,6 +43,24 @@ def test_product_fails_loudly_without_a_device(rt):
     assert err.value.code == -2  # RTK_ERR_NO_DEVICE: no CPU fallback exists
 
 
+def test_multi_gpu_entry_points_fail_loudly_without_a_device(rt):
+    """rtk_init_multi (several GPUs behind camera::render) has no CPU path either; argument errors come first."""
+    import torch
+
+    lib = rt.hip_lib()
+    handle = C.c_void_p()
+    devs = (C.c_int * 2)(0, 1)
+    assert lib.rtk_init_multi(0, devs, 0, C.byref(handle)) == -1 and not handle.value          # RTK_ERR_INVALID: no devices
+    assert lib.rtk_init_multi(2, devs, 7, C.byref(handle)) == -1                                # unknown gather mode
+    assert lib.rtk_init_multi(2, None, 0, C.byref(handle)) == -1
+    assert lib.rtk_multi_device_count(None) == 0 and lib.rtk_multi_destroy(None) == 0
+    assert lib.rtk_set_progress_callback(None, C.cast(None, rt.PROGRESS_FN), None, 0) == -1
+    if not torch.cuda.is_available():
+        with pytest.raises(rt.RtkError) as err:
+            rt.MultiRenderer([0, 1])
+        assert err.value.code == -2 and "no CPU path" in str(err.value)
+
+
 def test_package_never_touches_the_oracle():
     pkg = os.path.join(ROOT, "raytracingoneweekendapplication_amd")
     offenders = []
@@ -66,6 +84,61 @@ def test_camera_struct_layout_matches_c(rt):
     assert cam.defocus_angle == 0.0
     full = rt.Scene.build("book1_final").camera()
     assert (full.image_width, full.image_height, full.samples_per_pixel, full.max_depth) == (1920, 1080, 100, 50)
+
+
+def _initialize_literal(W, aspect, vfov, lookfrom, lookat, vup, defocus_angle, focus_dist):
+    """Camera.txt:136-175 restated line by line in Python floats (IEEE double, same operation order; vec3 `/ t` is
+    `(1/t) * v`, vec3.h:91-93; unit_vector(v) = v / v.length(), vec3.h:103-105; degrees_to_radians = d * pi / 180,
+    rtweekend.h:22-24)."""
+    import math
+
+    def sub(a, b): return [a[0] - b[0], a[1] - b[1], a[2] - b[2]]
+    def add(a, b): return [a[0] + b[0], a[1] + b[1], a[2] + b[2]]
+    def mul(t, a): return [t * a[0], t * a[1], t * a[2]]
+    def div(a, t): return mul(1 / t, a)
+    def cross(a, b): return [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]
+    def unit(a): return div(a, math.sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]))
+    pi = 3.1415926535897932385
+    image_height = int(W / aspect)                      # Camera.txt:137 (C++ int() truncates toward zero, as Python's)
+    image_height = 1 if image_height < 1 else image_height   # Camera.txt:138
+    theta = vfov * pi / 180.0
+    h = math.tan(theta / 2)
+    viewport_height = 2 * h * focus_dist
+    viewport_width = viewport_height * (float(W) / image_height)
+    w = unit(sub(lookfrom, lookat))
+    u = unit(cross(vup, w))
+    v = cross(w, u)
+    viewport_u = mul(viewport_width, u)
+    viewport_v = mul(viewport_height, [-v[0], -v[1], -v[2]])
+    du, dv = div(viewport_u, W), div(viewport_v, image_height)
+    upper_left = sub(sub(sub(lookfrom, mul(focus_dist, w)), div(viewport_u, 2)), div(viewport_v, 2))
+    pixel00 = add(upper_left, mul(0.5, add(du, dv)))
+    defocus_radius = focus_dist * math.tan((defocus_angle / 2) * pi / 180.0)
+    return image_height, pixel00, du, dv, mul(defocus_radius, u), mul(defocus_radius, v)
+
+
+def test_camera_derive_follows_initialize_over_odd_widths_and_aspects(rt):
+    """camera::derive() vs Camera.txt:136-175: image_height = int(image_width / aspect_ratio) with the `< 1 -> 1` rule
+    (Camera.txt:137-138) over widths and aspect ratios where the division does not come out whole, and the derived
+    viewport vectors bit for bit.  (Camera.txt itself includes windows.h and cannot be compiled here; this is its text
+    restated literally, not the build's own code.)"""
+    rng = np.random.default_rng(20251004)
+    cases = [(1024, 16.0 / 9.0), (1920, 16.0 / 9.0), (400, 16.0 / 9.0), (800, 1.0), (1, 1.0), (1, 16.0 / 9.0), (3, 7.0), (2, 2.5), (5, 1e6), (7, 0.013),
+             (1279, 2.39), (1000, 3.0), (999, 3.0), (1001, 3.0), (854, 1.7777), (64, 64.0), (63, 64.0), (65, 64.0)]
+    cases += [(int(rng.integers(1, 4000)), float(rng.uniform(0.05, 40.0))) for _ in range(200)]
+    view = dict(vfov=37.5, lookfrom=(13.0, 2.0, 3.0), lookat=(0.25, -0.5, 0.125), vup=(0.1, 1.0, -0.05), defocus_angle=0.6, focus_dist=9.75)
+    heights = set()
+    for W, aspect in cases:
+        cam = rt.derive_camera(W, aspect, spp=7, max_depth=3, **view)
+        H, p00, du, dv, ddu, ddv = _initialize_literal(W, aspect, view["vfov"], list(view["lookfrom"]), list(view["lookat"]), list(view["vup"]),
+                                                         view["defocus_angle"], view["focus_dist"])
+        assert cam.image_width == W and cam.image_height == H == max(1, int(W / aspect)), (W, aspect)
+        heights.add(H)
+        for got, want in ((cam.pixel00_loc, p00), (cam.pixel_delta_u, du), (cam.pixel_delta_v, dv), (cam.defocus_disk_u, ddu), (cam.defocus_disk_v, ddv)):
+            assert [got.x, got.y, got.z] == want, (W, aspect)          # same doubles, not merely close
+        assert [cam.center.x, cam.center.y, cam.center.z] == list(view["lookfrom"]) and cam.pixel_samples_scale == 1.0 / 7
+        assert cam.samples_per_pixel == 7 and cam.max_depth == 3 and cam.defocus_angle == 0.6
+    assert 1 in heights and len(heights) > 100     # the clamp to 1 was exercised (W / aspect < 1) as well as many truncations
 
 
 @pytest.mark.parametrize("case", IMAGE_CASES, ids=[c[0] for c in IMAGE_CASES])

@@ -30,6 +30,17 @@ def rmse(a, b):
     return float(np.sqrt(np.mean((a - b) ** 2)))
 
 
+def _assert_culling_counters(got, exact):
+    """Work counters of a kernel that culls with CONSERVATIVE f32 boxes (the MIXED program) against the exact counters
+    of the same hierarchy (oracle / f64-box kernel): everything a closest hit determines -- samples, segments, surface
+    interactions, RNG draws -- is an equal integer; box and primitive tests can only be MORE (an enlarged box admits a
+    superset of rays, and an extra primitive test never produces a hit), by well under one per cent."""
+    for key in ("samples", "segments", "surface_hits", "rng_draws", "quad_tests", "triangle_tests", "xform_enters", "medium_tests", "noise_calls", "texel_fetches"):
+        assert got[key] == exact[key], key
+    for key in ("box_tests", "sphere_tests"):
+        assert exact[key] <= got[key] <= exact[key] * 1.01 + 8, (key, got[key], exact[key])
+
+
 @pytest.fixture(scope="module")
 def scenes(rt):
     cache = {}
@@ -198,7 +209,7 @@ def test_error_behaviour(rt, renderer, scenes, tmp_path):
 
 
 # ------------------------------------------------------------------ BASELINE sizes
-def _full_size_checks(rt, orc, renderer, scene, cam, n_probe=48):
+def _full_size_checks(rt, orc, renderer, scene, cam, n_probe=48, probe_seed=1234):
     """Full-size render checked through properties that do not need a full CPU render:
     exact per-pixel agreement with the oracle on a random pixel subset (every pixel is an
     independent function of (scene, camera, seed, pixel)), exact sample count, and invariance
@@ -213,7 +224,7 @@ def _full_size_checks(rt, orc, renderer, scene, cam, n_probe=48):
     torch.cuda.synchronize()
     img = image.cpu().numpy()
     assert np.isfinite(img).all() and (img >= 0).all()
-    rng = np.random.default_rng(1234)
+    rng = np.random.default_rng(probe_seed)
     rgb = (C.c_double * 3)()
     worst = 0.0
     for _ in range(n_probe):
@@ -237,6 +248,25 @@ def test_config2_full_size_properties(rt, orc, renderer, scenes):
     # furnace bound: every albedo <= 1 and nothing emits, so no pixel can exceed the background colour
     assert (img <= np.array([0.7, 0.8, 1.0]) + 1e-12).all()
     assert 0.2 < img.mean() < 0.6
+    # ... and THE KERNEL bench.py TIMES: fast order + MIXED program (rtk_render_kernel<double, 256u, false, true>) at
+    # the headline size, probed against the oracle's per-sample values of the reference scene; same bytes as above
+    info = renderer.upload_fast(scene, cam.center)
+    assert info["exact"] and renderer.kernel_name() == "rtk_render_kernel<double, 256u, false, true>"
+    timed = _full_size_checks(rt, orc, renderer, scene, cam, n_probe=24, probe_seed=99)
+    assert np.array_equal(timed, img)
+    # its counting build at full size against the exact counters of the same hierarchy (f64-box counting kernel)
+    import torch
+    dev = torch.device("cuda", 0)
+    buf = torch.empty((1080, 1920, 3), dtype=torch.float64, device=dev)
+    got = []
+    for variant in (0, 1 << 20):
+        cnt = torch.zeros(12, dtype=torch.int64, device=dev)
+        renderer.render_device(cam, buf.data_ptr(), 0, d_counters=cnt.data_ptr(), variant=variant)
+        torch.cuda.synchronize()
+        assert np.array_equal(buf.cpu().numpy(), img)
+        got.append(dict(zip(rt.COUNTER_FIELDS, cnt.tolist())))
+    assert got[0]["samples"] == 1920 * 1080 * 100
+    _assert_culling_counters(got[0], got[1])
 
 
 def test_config1_and_config3_reduced_spp_properties(rt, orc, renderer, scenes):
@@ -252,6 +282,31 @@ def test_config1_and_config3_reduced_spp_properties(rt, orc, renderer, scenes):
     renderer.upload(scene)
     img = _full_size_checks(rt, orc, renderer, scene, cam, n_probe=32)
     assert img.max() <= 15.0 + 1e-9     # nothing can be brighter than the light (emit 15)
+
+
+def test_config4_and_config5_full_resolution_reduced_spp_properties(rt, orc, renderer, scenes):
+    """configs[3] (triangle mesh, 1920x1080) and configs[4] (book-2 final: media, Perlin, motion blur, image texture,
+    instances; 1920x1080) at full resolution and 8 of their 256 / 1000 spp, in the order and with the kernels bench.py
+    times there (reference order; boxes-in-LDS kernels, the programs do not fit LDS): exact per-pixel agreement with the
+    oracle on random pixels, finiteness, and brightness bounds the scenes imply."""
+    scene = scenes("mesh")
+    cam = scene.camera(0, 0, 8, 0)
+    assert (cam.image_width, cam.image_height, cam.max_depth) == (1920, 1080, 10)
+    renderer.upload(scene)
+    assert "false, false" in renderer.kernel_name() and int(renderer.kernel_name().split(",")[1].strip(" u")) & 1024   # F_LDS_BOXES
+    img = _full_size_checks(rt, orc, renderer, scene, cam, n_probe=32)
+    assert img.mean() > 0.01
+    # the fast order renders the same bytes at this size too (not provable for triangles: float determinant, triangle.h:72,77)
+    renderer.upload_fast(scene, cam.center)
+    fast = _full_size_checks(rt, orc, renderer, scene, cam, n_probe=8, probe_seed=5)
+    assert np.array_equal(fast, img)
+    scene = scenes("book2_final")
+    cam = scene.camera(0, 0, 8, 0)
+    assert (cam.image_width, cam.image_height, cam.max_depth) == (1920, 1080, 10)
+    renderer.upload(scene)
+    assert "1151u" in renderer.kernel_name()
+    img = _full_size_checks(rt, orc, renderer, scene, cam, n_probe=32)
+    assert img.max() <= 7.0 + 1e-9 and img.mean() > 0.005    # nothing is brighter than the light (emit 7, main.cpp:292)
 
 
 def test_device_hit_records_match_reference_known_answers(rt, renderer, tmp_path):
@@ -313,7 +368,13 @@ def test_fast_order_on_the_device(rt, orc, renderer, scenes, case):
     assert (feat & 128) or feat == 256 or (feat & ~512) == 69
     fused, fused8, fcnt = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, count=True)
     fused_fast, _, _ = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64)
-    assert np.array_equal(fused, gpu) and np.array_equal(fused8, gpu8) and np.array_equal(fused_fast, gpu) and fcnt == counters
+    assert np.array_equal(fused, gpu) and np.array_equal(fused8, gpu8) and np.array_equal(fused_fast, gpu)
+    if feat == 256:   # MIXED program: `count=True` ran the counting build of the F_F32_BOX kernel itself
+        _assert_culling_counters(fcnt, counters)
+        _, _, exact_cnt = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, count=True, variant=1 << 20)   # f64 boxes
+        assert exact_cnt == counters
+    else:
+        assert fcnt == counters
     if not fast.info["has_media"]:
         renderer.upload(scene)
         base, base8, bcnt = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, count=True)
@@ -383,6 +444,15 @@ def test_mixed_program_kernel_is_used_and_bit_identical(rt, orc, renderer, scene
     assert np.array_equal(fused, base) and np.array_equal(in_global, base)
     ref, ref8, _ = orc.render(scene.desc_ptr, cam, RENDER_SEED, 8)
     assert rmse(mixed, ref) < F64_RMSE_BOUND and np.array_equal(mixed8, ref8)
+    # the counting build of the MIXED kernel (rtk_render_kernel<double, 256u, true, true>) against the oracle executing
+    # the same re-grouped hierarchy: same image, closest-hit counters equal, culling counters a tight superset
+    fast = scene.fast_order(cam.center)
+    _, _, ocnt = orc.render(fast.desc_ptr, cam, RENDER_SEED, 8)
+    counted, counted8, mcnt = renderer.render_host(cam, count=True)
+    assert np.array_equal(counted, base) and np.array_equal(counted8, base8)
+    _assert_culling_counters(mcnt, ocnt)
+    in_global_counted, _, gcnt = renderer.render_host(cam, count=True, variant=1)
+    assert np.array_equal(in_global_counted, base) and gcnt == mcnt
 
 
 def test_mixed_program_moving_spheres_and_far_cameras(rt, orc, renderer):
@@ -457,6 +527,50 @@ def test_cpp_camera_render_through_the_drop_in_api(rt, tmp_path):
     assert not fog["exact"] and not fog["auto_used_fast"] and fog["auto_identical"]
     assert abs(fog["mean_fast"] - fog["mean_ref"]) < 0.03 * fog["mean_ref"]
     assert clear["mean_ref"] > 0.05
+    # camera::devices = {0, 0} / {0, 0, 0}: render() splits the image itself (rtk_render_multi) -- same doubles, same bytes;
+    # camera::progress is fed from the work-item counters and ends at the total (Camera.txt:102-106 prints a percentage)
+    for verdict in (clear, fog):
+        assert verdict["two_devices_identical"] and verdict["three_devices_identical"] and verdict["bytes_identical"]
+        assert verdict["progress_calls"] >= 1 and verdict["progress_monotone"] and verdict["progress_reached_total"]
+
+
+@pytest.mark.parametrize("devices,gather,real", [([0, 0], "auto", "f64"), ([0, 0, 0, 0, 0], "peer", "f64"), ([0, 0, 0], "auto", "f32"), ([0], "rccl", "f64"), ([0], "auto", "f64")])
+def test_render_multi_behind_the_c_abi_reproduces_the_one_gpu_bytes(rt, renderer, scenes, devices, gather, real):
+    """rtk_init_multi / rtk_render_multi (one host thread, one stream per device slot, replicated upload -- the SAH pass
+    once --, compact tile buffers, ONE gather to the first device, rtk_tiles_unpermute there).  On this one-GPU box the
+    device is listed several times (peer-copy gather; RCCL refuses duplicate devices) and, for the RCCL transport, once
+    with the gather forced through a 1-rank ncclGather.  The image must not depend on any of it."""
+    scene = scenes("book1_final")
+    cam = scene.camera(100, 60, 10, 50)      # 104 tiles: ragged against 2, 3 and 5 ranks; 10 spp: two sample chunks
+    mode = rt.RTK_REAL_F64 if real == "f64" else rt.RTK_REAL_F32
+    for fast in (False, True):
+        renderer.upload_fast(scene, cam.center) if fast else renderer.upload(scene)
+        whole, whole8, _ = renderer.render_host(cam, real_mode=mode)
+        multi = rt.MultiRenderer(devices, {"auto": rt.GATHER_AUTO, "peer": rt.GATHER_PEER, "rccl": rt.GATHER_RCCL}[gather])
+        assert multi.uses_rccl == (gather == "rccl")
+        info = multi.upload_fast(scene, cam.center) if fast else multi.upload(scene)
+        assert multi.kernel_name(mode) == renderer.kernel_name(mode) and (not fast or info["exact"])
+        seen = []
+        multi.set_progress(lambda done, total: seen.append((done, total)), interval_ms=1)
+        image, image8 = multi.render_host(cam, real_mode=mode)
+        again, _ = multi.render_host(cam, real_mode=mode)       # buffers and the learned tile order are reused
+        assert np.array_equal(image, whole) and np.array_equal(image8, whole8) and np.array_equal(again, whole)
+        assert seen and seen[-1][0] == seen[-1][1] > 0 and all(a[0] <= b[0] for a, b in zip(seen, seen[1:]))
+        multi.close()
+
+
+def test_render_multi_error_behaviour(rt):
+    with pytest.raises(rt.RtkError) as e:
+        rt.MultiRenderer([0, 99])
+    assert e.value.code == -1                 # device out of range
+    with pytest.raises(rt.RtkError) as e:
+        rt.MultiRenderer([0, 0], rt.GATHER_RCCL)
+    assert e.value.code == -4 and "more than once" in str(e.value)     # RCCL cannot run two ranks on one device
+    multi = rt.MultiRenderer([0, 0])
+    cam = rt.Scene.build("three_spheres").camera(16, 16, 1, 2)
+    with pytest.raises(rt.RtkError) as e:
+        multi.render_host(cam)
+    assert e.value.code == -5                 # RTK_ERR_NO_SCENE
 
 
 def test_boxes_in_lds_kernel_for_programs_larger_than_lds(rt, orc, renderer, scenes):

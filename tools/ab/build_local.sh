@@ -7,7 +7,7 @@ C=raytracingoneweekendapplication_amd/csrc
 mkdir -p tools/ab/build
 for spec in "$@"; do
   n=${spec%%:*}; flags=${spec#*:}; [ "$flags" = "$spec" ] && flags=""
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $flags -Iinclude -I$C $C/rtk_api.cpp $C/rtk_optimize.cpp $C/rtk_trace.hip -o tools/ab/build/$n.so &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $flags -Iinclude -I$C $C/rtk_api.cpp $C/rtk_multi.cpp $C/rtk_optimize.cpp $C/rtk_trace.hip -o tools/ab/build/$n.so &
 done
 wait
 ls -la tools/ab/build

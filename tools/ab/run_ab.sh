@@ -7,7 +7,7 @@ C=raytracingoneweekendapplication_amd/csrc
 for n in "$@"; do
   mkdir -p gpurun_out/ab/$n
   cp tools/ab/$n.hip gpurun_out/ab/$n/rtk_trace.hip
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Iinclude -I$C $C/rtk_api.cpp $C/rtk_optimize.cpp gpurun_out/ab/$n/rtk_trace.hip -o gpurun_out/ab/$n.so &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Iinclude -I$C $C/rtk_api.cpp $C/rtk_multi.cpp $C/rtk_optimize.cpp gpurun_out/ab/$n/rtk_trace.hip -o gpurun_out/ab/$n.so &
 done
 wait
 CFG=${AB_CONFIG:-c2}; SPP=${AB_SPP:-0}; REAL=${AB_REAL:-f64}

@@ -12,7 +12,7 @@ os.makedirs(os.path.dirname(prof_lib), exist_ok=True)
 csrc = os.path.join(ROOT, "raytracingoneweekendapplication_amd", "csrc")
 if not os.path.exists(prof_lib) or os.path.getmtime(prof_lib) < os.path.getmtime(os.path.join(csrc, "rtk_trace.hip")):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DRTK_PROFILE",
-                           "-I" + os.path.join(ROOT, "include"), "-I" + csrc, os.path.join(csrc, "rtk_api.cpp"), os.path.join(csrc, "rtk_optimize.cpp"), os.path.join(csrc, "rtk_trace.hip"), "-o", prof_lib])
+                           "-I" + os.path.join(ROOT, "include"), "-I" + csrc, os.path.join(csrc, "rtk_api.cpp"), os.path.join(csrc, "rtk_multi.cpp"), os.path.join(csrc, "rtk_optimize.cpp"), os.path.join(csrc, "rtk_trace.hip"), "-o", prof_lib])
 os.environ["RTK_HIP_LIB"] = prof_lib
 import torch
 import raytracingoneweekendapplication_amd as rt

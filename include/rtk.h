@@ -203,7 +203,8 @@ typedef struct rtk_render_opts {
                              * hand-out); bits 3-4 = chunk size (0: 8 samples, 1: 4, 2: 2, 3: 16);
                              * bits 8-13 = scheduler loop-exit thresholds, bits 14-16 = refill batch size, bits 17-19 = lanes needed
                              * for a sphere step inside the box loop, bit 20 = f64 boxes instead of the MIXED program, bit 21 = no boxes-in-LDS
-                             * kernel for programs larger than LDS (see csrc/rtk_trace.hip) */
+                             * kernel for programs larger than LDS (see csrc/rtk_trace.hip); bit 22 = write the compact tile
+                             * buffer [tiles][3][64] also when n_ranks == 1 (rtk_multi's one-device RCCL path; d_rgb8 NULL) */
     void* stream;           /* hipStream_t, NULL = default stream */
 } rtk_render_opts;
 

@@ -871,7 +871,8 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
     if (cam->image_width <= 0 || cam->image_height <= 0 || cam->samples_per_pixel <= 0 || cam->samples_per_pixel > 32767 || cam->max_depth < 0)
         return fail(RTK_ERR_INVALID, "rtk_render_device: bad camera dimensions (samples_per_pixel must be 1..32767)");
     if (opts->n_ranks < 1 || opts->rank < 0 || opts->rank >= opts->n_ranks) return fail(RTK_ERR_INVALID, "rtk_render_device: bad rank %d of %d", opts->rank, opts->n_ranks);
-    if (opts->n_ranks > 1 && d_rgb8) return fail(RTK_ERR_INVALID, "rtk_render_device: d_rgb8 must be null when n_ranks > 1 (use rtk_tiles_unpermute)");
+    const bool compact_out = opts->n_ranks > 1 || (opts->variant & (1 << 22)) != 0;  // variant bit 22: the tile-buffer layout for a single rank too
+    if (compact_out && d_rgb8) return fail(RTK_ERR_INVALID, "rtk_render_device: d_rgb8 must be null when n_ranks > 1 (use rtk_tiles_unpermute)");
     if (opts->count_work && !d_counters) return fail(RTK_ERR_INVALID, "rtk_render_device: count_work needs d_counters");
     if (opts->real_mode != RTK_REAL_F64 && opts->real_mode != RTK_REAL_F32) return fail(RTK_ERR_INVALID, "rtk_render_device: unknown real_mode %d", opts->real_mode);
     RTK_HIP(hipSetDevice(ctx->device));
@@ -881,7 +882,7 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
     tm.rank = opts->rank;
     tm.n_ranks = opts->n_ranks;
     tm.n_tiles_local = int32_t(rtk_tiles_per_rank(cam->image_width, cam->image_height, opts->n_ranks));
-    tm.compact = opts->n_ranks > 1 ? 1 : 0;
+    tm.compact = compact_out ? 1 : 0;
     tm.order_in_lds = 0;
     tm.order_lds_offset = 0;
     // Split every pixel's samples into chunks of 8 (at most 64 chunks) so that no lane is stuck with a whole
@@ -1093,11 +1094,10 @@ int rtk_scene_info(rtk_ctx* ctx, int32_t* n_program_ops, int64_t* bytes_f64, int
 
 const char* rtk_kernel_name(rtk_ctx* ctx, int real_mode, int variant) {
     if (!ctx || !ctx->has_scene) return "";
-    const bool f64 = real_mode == RTK_REAL_F64;
-    const bool mixed = f64 && ctx->scene64.view.program_mixed != nullptr && (variant & (1 << 20)) == 0;
-    const bool lds = (variant & 1) == 0 && (f64 ? program_fits_lds(ctx->scene64.view, mixed) : program_fits_lds(ctx->scene32.view, false));
-    const bool has_box_cache = f64 ? ctx->scene64.view.box_cache != nullptr : ctx->scene32.view.box_cache != nullptr;
-    return render_kernel_name(f64, ctx->features, false, lds, mixed, has_box_cache, uint32_t(variant));
+    const bool allow_lds = (variant & 1) == 0;
+    const uint32_t diag = uint32_t(variant) & 0x3FFF00u;
+    return real_mode == RTK_REAL_F64 ? render_kernel_name<double>(ctx->scene64.view, ctx->features, false, allow_lds, diag)
+                                     : render_kernel_name<float>(ctx->scene32.view, ctx->features, false, allow_lds, diag);
 }
 
 }  // extern "C"

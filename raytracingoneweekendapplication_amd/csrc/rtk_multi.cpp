@@ -250,6 +250,7 @@ int rtk_render_multi_device(rtk_multi* m, const rtk_camera* cam, const rtk_rende
         o.rank = i;
         o.n_ranks = n;
         o.stream = m->streams[size_t(i)];
+        if (n == 1) o.variant |= 1 << 22;  // one device through the gather path (RCCL forced): still a tile buffer
         void* target = i == 0 ? static_cast<void*>(gathered) : m->compact[size_t(i)];
         rc = rtk_render_device(m->ctxs[size_t(i)], cam, &o, target, nullptr, nullptr);
         if (rc != RTK_OK) return rc;

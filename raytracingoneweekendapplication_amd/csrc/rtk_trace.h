@@ -28,10 +28,6 @@ template <typename real>
 hipError_t launch_resolve(const void* partial, const TileMap& tmap, int width, int height, double samples_scale, void* out_linear, uint8_t* out_rgb8,
                           hipStream_t stream);
 
-// Whether the traversal program of `sc` can be staged in one CU's LDS.
-template <typename real>
-bool program_fits_lds(const SceneView<real>& sc, bool mixed = false);
-
 // Known-answer helper: closest hit of the scene root for n caller-supplied rays (device buffers).
 template <typename real>
 hipError_t launch_debug_hit(const SceneView<real>& sc, int n, const double* d_rays, const uint32_t* d_keys, double* d_out, unsigned long long* d_draws,
@@ -41,7 +37,9 @@ template <typename real>
 hipError_t launch_unpermute(const void* gathered, int width, int height, int n_ranks, long long tiles_per_rank, void* out_linear, uint8_t* out_rgb8,
                             hipStream_t stream);
 
-const char* render_kernel_name(bool f64, uint32_t features, bool count, bool lds, bool mixed, bool has_box_cache, uint32_t diag);
+// Symbol name of the render kernel launch_render would launch for these arguments (the one decision function serves both).
+template <typename real>
+const char* render_kernel_name(const SceneView<real>& sc, uint32_t features, bool count, bool allow_lds, uint32_t diag);
 
 }  // namespace rtk
 

@@ -1024,16 +1024,23 @@ RTK_DEV void store_partial(real* __restrict__ partial, int item, int pix, V3<rea
     base[128] = sum.z;
 }
 
+#ifndef RTK_THREADS_ALL_F64
+#define RTK_THREADS_ALL_F64 512   // workgroup bound of the full-feature f64 kernel (A/B builds: 768 = 3 waves per SIMD, 1024 = 4)
+#endif
 // Workgroup-size bound = register budget: 1024 threads -> 4 waves per SIMD, 128 VGPRs; 768 -> 3 waves, 168 VGPRs;
 // 512 -> 2 waves, 256 VGPRs.  Measured on C2 (lean f64 kernel): 2 waves 93.8 ms, 3 waves 73.5 ms, 4 waves 68.5 ms
 // per frame (the 4-wave build spills a few values in the shade path).  Same-box A/B for the other f64 kernels
 // (tools/ab/run_ab.sh): quad/box subset on C3 43.3 ms at 4 waves vs 48.7 at 3; mesh subset on C4 no difference;
 // the full-feature kernel, which needs far more registers (~560 B/lane of spills at 168), is fastest at 2 waves.
+template <typename real>
+constexpr int max_threads_of(uint32_t feat) {
+    const uint32_t scene_feat = feat & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE | F_LDS_BOXES);
+    if (sizeof(real) == 8) return scene_feat == kFeatAll ? RTK_THREADS_ALL_F64 : ((scene_feat == kFeatLean || scene_feat == kFeatQuadBox) ? 1024 : 768);
+    return 768;
+}
 template <typename real, uint32_t FEAT>
 constexpr int max_threads() {
-    constexpr uint32_t scene_feat = FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE | F_LDS_BOXES);
-    if (sizeof(real) == 8) return scene_feat == kFeatAll ? 512 : ((scene_feat == kFeatLean || scene_feat == kFeatQuadBox) ? 1024 : 768);
-    return 768;
+    return max_threads_of<real>(FEAT);
 }
 
 template <typename real, uint32_t FEAT_ALL, bool COUNT, bool IN_LDS>
@@ -1042,7 +1049,10 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                                                           unsigned int* __restrict__ tile_counter, const int32_t* __restrict__ tile_order,
                                                           unsigned int* __restrict__ tile_cost, uint32_t diag) {
     extern __shared__ __align__(16) unsigned char lds_program[];
-    constexpr uint32_t FEAT = FEAT_ALL & ~uint32_t(F_LDS_BOXES);
+#ifndef RTK_DEV_MASK_OFF
+#define RTK_DEV_MASK_OFF 0u   // register-pressure experiments (tools/kernel_resources.py): feature bits compiled out of every kernel
+#endif
+    constexpr uint32_t FEAT = FEAT_ALL & ~uint32_t(F_LDS_BOXES) & ~uint32_t(RTK_DEV_MASK_OFF);
     constexpr bool SPLIT = (FEAT_ALL & F_LDS_BOXES) != 0;  // boxes, kinds and the rank table in LDS; everything else of the program in HBM/L2
     static_assert(!SPLIT || (!IN_LDS && (FEAT & F_F32_BOX) == 0), "F_LDS_BOXES: for programs that do not fit LDS");
     constexpr bool MIXED = (FEAT & F_F32_BOX) != 0;  // the MIXED program: f32 culling boxes, 32-byte units (f64, sphere-only scenes)
@@ -1746,14 +1756,6 @@ template <typename real>
 static size_t split_lds_bytes(const SceneView<real>& sc) {
     return size_t(sc.n_cached_boxes) * sizeof(BoxRec<real>) + ((size_t(sc.n_kind_words) * 4 + 7) & ~size_t(7)) + size_t(sc.n_rank_words) * 8;
 }
-// Whether a launch that cannot stage the whole program uses the boxes-in-LDS kernel: the upload built the tables (the
-// program is larger than LDS, its boxes are not) and the kernel family has the instantiation (mesh and full-feature).
-template <typename real>
-static bool use_lds_boxes(const SceneView<real>& sc, uint32_t feat, bool lds, bool count, uint32_t diag) {
-    const uint32_t scene = feat & ~uint32_t(F_FMA_BOX | F_MATTE);
-    return !lds && !count && sc.box_cache != nullptr && (scene == kFeatMesh || scene == kFeatAll) && (diag & (1u << 21)) == 0;
-}
-
 template <typename real, uint32_t FEAT, bool COUNT, bool IN_LDS>
 static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>* cam, const TileMap& tmap, uint32_t seed, void* partial,
                              unsigned long long* counters, unsigned int* tile_counter, const int32_t* tile_order, unsigned int* tile_cost, uint32_t diag,
@@ -1781,11 +1783,6 @@ static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>* c
     return hipGetLastError();
 }
 
-template <typename real>
-bool program_fits_lds(const SceneView<real>& sc, bool mixed) {
-    return lds_image_bytes(sc, mixed) <= size_t(kLdsBytesPerCU);
-}
-
 // The MIXED program is used whenever the upload built one (f64, sphere-only scene, fast order); variant bit 20 keeps
 // the f64 boxes instead (A/B).
 template <typename real>
@@ -1806,51 +1803,74 @@ static uint32_t kernel_features(uint32_t features, bool count, bool mixed) {
     return kFeatAll | fma;
 }
 
+// Which instantiation a launch uses -- decided in ONE place, for the launcher and for rtk_kernel_name alike.
+struct KernelChoice {
+    uint32_t feat;   // template FEAT word, F_LDS_BOXES included
+    bool count, in_lds;
+};
+template <typename real>
+static KernelChoice choose_kernel(const SceneView<real>& sc, uint32_t features, bool count, bool allow_lds, uint32_t diag) {
+    const bool mixed = use_mixed_program(sc, diag);
+    // the matte variants pay off in f64 only (C3: f64 34.8 -> 31.9 ms, f32 26.6 -> 36.5 ms at one more wave per SIMD)
+    KernelChoice k{kernel_features(sizeof(real) == 8 ? features : (features & ~uint32_t(F_MATTE)), count, mixed), count, false};
+    const uint32_t scene = k.feat & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE);
+    const bool fits = allow_lds && lds_image_bytes(sc, (k.feat & F_F32_BOX) != 0) <= size_t(kLdsBytesPerCU);
+    if (count) {  // counting builds: only the MIXED one stages its program (it is the timed kernel with counters)
+        k.in_lds = fits && (k.feat & F_F32_BOX) != 0;
+        return k;
+    }
+    k.in_lds = fits;
+    // a program larger than LDS whose box records are not: the boxes-in-LDS kernel (mesh and full-feature families)
+    if (!fits && sc.box_cache != nullptr && (scene == kFeatMesh || scene == kFeatAll) && (diag & (1u << 21)) == 0) k.feat |= uint32_t(F_LDS_BOXES);
+    return k;
+}
+
 template <typename real, uint32_t FEAT>
-static hipError_t launch_feat(const SceneView<real>& sc, const CameraRec<real>* cam, const TileMap& tmap, uint32_t seed, bool count, bool lds, uint32_t diag,
+static hipError_t launch_feat(const KernelChoice& k, const SceneView<real>& sc, const CameraRec<real>* cam, const TileMap& tmap, uint32_t seed, uint32_t diag,
                               void* partial, unsigned long long* counters, unsigned int* tile_counter, const int32_t* tile_order, unsigned int* tile_cost,
                               hipStream_t stream) {
+#define RTK_GO(FF, C, L) return launch_one<real, FF, C, L>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream)
     if constexpr ((FEAT & ~uint32_t(F_FMA_BOX)) == kFeatAll) {
-        if (count) return launch_one<real, FEAT, true, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
+        if (k.count) RTK_GO(FEAT, true, false);
     }
     if constexpr ((FEAT & F_F32_BOX) != 0) {  // the timed sphere-scene kernel with work counters: same program, same steps, same LDS staging
-        if (count)
-            return lds ? launch_one<real, FEAT, true, true>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream)
-                       : launch_one<real, FEAT, true, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
+        if (k.count) {
+            if (k.in_lds) RTK_GO(FEAT, true, true);
+            RTK_GO(FEAT, true, false);
+        }
     }
     if constexpr ((FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatMesh || (FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatAll) {
-        if (use_lds_boxes(sc, FEAT, lds, count, diag))
-            return launch_one<real, FEAT | uint32_t(F_LDS_BOXES), false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
+        if (k.feat & F_LDS_BOXES) RTK_GO(FEAT | uint32_t(F_LDS_BOXES), false, false);
     }
-    return lds ? launch_one<real, FEAT, false, true>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream)
-               : launch_one<real, FEAT, false, false>(sc, cam, tmap, seed, partial, counters, tile_counter, tile_order, tile_cost, diag, stream);
+    if (k.in_lds) RTK_GO(FEAT, false, true);
+    RTK_GO(FEAT, false, false);
+#undef RTK_GO
 }
 
 template <typename real>
 hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>* cam, const TileMap& tmap, uint32_t seed, uint32_t features, bool count,
                          bool allow_lds, uint32_t diag, void* partial, unsigned long long* counters, unsigned int* tile_counter,
                          const int32_t* tile_order, unsigned int* tile_cost, hipStream_t stream) {
-    const bool mixed = use_mixed_program(sc, diag);
-    // the matte variants pay off in f64 only (C3: f64 34.8 -> 31.9 ms, f32 26.6 -> 36.5 ms at one more wave per SIMD)
-    const uint32_t feat = kernel_features(sizeof(real) == 8 ? features : (features & ~uint32_t(F_MATTE)), count, mixed);
-    const bool lds = allow_lds && program_fits_lds(sc, (feat & F_F32_BOX) != 0);
+    const KernelChoice k = choose_kernel(sc, features, count, allow_lds, diag);
 #define RTK_LAUNCH_CASE(F) \
-    case F: return launch_feat<real, F>(sc, cam, tmap, seed, count, lds, diag, partial, counters, tile_counter, tile_order, tile_cost, stream);
-    switch (feat) {
+    case F: return launch_feat<real, F>(k, sc, cam, tmap, seed, diag, partial, counters, tile_counter, tile_order, tile_cost, stream);
+    switch (k.feat & ~uint32_t(F_LDS_BOXES)) {
+#if !defined(RTK_DEV_ONLY_ALL)   // tools/kernel_resources.py -DRTK_DEV_ONLY_ALL: only the full-feature family (quick register experiments)
         RTK_LAUNCH_CASE(kFeatLean)
         RTK_LAUNCH_CASE(kFeatQuadBox)
         RTK_LAUNCH_CASE(kFeatQuadBox | F_MATTE)
         RTK_LAUNCH_CASE(kFeatMesh)
-        RTK_LAUNCH_CASE(kFeatAll)
         RTK_LAUNCH_CASE(kFeatLean | F_FMA_BOX)
         RTK_LAUNCH_CASE(kFeatMesh | F_FMA_BOX)
         RTK_LAUNCH_CASE(kFeatMesh | F_MATTE)
         RTK_LAUNCH_CASE(kFeatMesh | F_FMA_BOX | F_MATTE)
-        RTK_LAUNCH_CASE(kFeatAll | F_FMA_BOX)
         case kFeatLean | F_F32_BOX:
             if constexpr (sizeof(real) == 8)
-                return launch_feat<real, kFeatLean | F_F32_BOX>(sc, cam, tmap, seed, count, lds, diag, partial, counters, tile_counter, tile_order, tile_cost, stream);
+                return launch_feat<real, kFeatLean | F_F32_BOX>(k, sc, cam, tmap, seed, diag, partial, counters, tile_counter, tile_order, tile_cost, stream);
             break;
+#endif
+        RTK_LAUNCH_CASE(kFeatAll)
+        RTK_LAUNCH_CASE(kFeatAll | F_FMA_BOX)
     }
 #undef RTK_LAUNCH_CASE
     return hipErrorInvalidValue;
@@ -1859,8 +1879,16 @@ template hipError_t launch_render<double>(const SceneView<double>&, const Camera
                                           unsigned long long*, unsigned int*, const int32_t*, unsigned int*, hipStream_t);
 template hipError_t launch_render<float>(const SceneView<float>&, const CameraRec<float>*, const TileMap&, uint32_t, uint32_t, bool, bool, uint32_t, void*,
                                          unsigned long long*, unsigned int*, const int32_t*, unsigned int*, hipStream_t);
-template bool program_fits_lds<double>(const SceneView<double>&, bool);
-template bool program_fits_lds<float>(const SceneView<float>&, bool);
+
+template <typename real>
+const char* render_kernel_name(const SceneView<real>& sc, uint32_t features, bool count, bool allow_lds, uint32_t diag) {
+    static thread_local char name[96];
+    const KernelChoice k = choose_kernel(sc, features, count, allow_lds, diag);
+    snprintf(name, sizeof name, "rtk_render_kernel<%s, %uu, %s, %s>", sizeof(real) == 8 ? "double" : "float", k.feat, k.count ? "true" : "false", k.in_lds ? "true" : "false");
+    return name;
+}
+template const char* render_kernel_name<double>(const SceneView<double>&, uint32_t, bool, bool, uint32_t);
+template const char* render_kernel_name<float>(const SceneView<float>&, uint32_t, bool, bool, uint32_t);
 
 template <typename real>
 hipError_t launch_resolve(const void* partial, const TileMap& tmap, int width, int height, double samples_scale, void* out_linear, uint8_t* out_rgb8,
@@ -1896,15 +1924,5 @@ hipError_t launch_unpermute(const void* gathered, int width, int height, int n_r
 }
 template hipError_t launch_unpermute<double>(const void*, int, int, int, long long, void*, uint8_t*, hipStream_t);
 template hipError_t launch_unpermute<float>(const void*, int, int, int, long long, void*, uint8_t*, hipStream_t);
-
-const char* render_kernel_name(bool f64, uint32_t features, bool count, bool lds, bool mixed, bool has_box_cache, uint32_t diag) {
-    static thread_local char name[96];
-    uint32_t feat = kernel_features(f64 ? features : (features & ~uint32_t(F_MATTE)), count, mixed && f64);
-    const uint32_t scene = feat & ~uint32_t(F_FMA_BOX | F_MATTE);
-    if (!lds && !count && has_box_cache && (scene == kFeatMesh || scene == kFeatAll) && (diag & (1u << 21)) == 0) feat |= uint32_t(F_LDS_BOXES);
-    const bool counting_in_lds = (feat & F_F32_BOX) != 0;  // the only counting instantiation that stages its program
-    snprintf(name, sizeof name, "rtk_render_kernel<%s, %uu, %s, %s>", f64 ? "double" : "float", feat, count ? "true" : "false", (lds && (!count || counting_in_lds)) ? "true" : "false");
-    return name;
-}
 
 }  // namespace rtk

@@ -17,10 +17,6 @@ hipError_t launch_resolve(const void*, const TileMap&, int, int, double, void*, 
 template hipError_t launch_resolve<double>(const void*, const TileMap&, int, int, double, void*, uint8_t*, hipStream_t);
 template hipError_t launch_resolve<float>(const void*, const TileMap&, int, int, double, void*, uint8_t*, hipStream_t);
 template <typename real>
-bool program_fits_lds(const SceneView<real>&, bool) { return false; }
-template bool program_fits_lds<double>(const SceneView<double>&, bool);
-template bool program_fits_lds<float>(const SceneView<float>&, bool);
-template <typename real>
 hipError_t launch_debug_hit(const SceneView<real>&, int, const double*, const uint32_t*, double*, unsigned long long*, hipStream_t) { return hipErrorNotSupported; }
 template hipError_t launch_debug_hit<double>(const SceneView<double>&, int, const double*, const uint32_t*, double*, unsigned long long*, hipStream_t);
 template hipError_t launch_debug_hit<float>(const SceneView<float>&, int, const double*, const uint32_t*, double*, unsigned long long*, hipStream_t);
@@ -28,6 +24,9 @@ template <typename real>
 hipError_t launch_unpermute(const void*, int, int, int, long long, void*, uint8_t*, hipStream_t) { return hipErrorNotSupported; }
 template hipError_t launch_unpermute<double>(const void*, int, int, int, long long, void*, uint8_t*, hipStream_t);
 template hipError_t launch_unpermute<float>(const void*, int, int, int, long long, void*, uint8_t*, hipStream_t);
-const char* render_kernel_name(bool, uint32_t, bool, bool, bool, bool, uint32_t) { return ""; }
+template <typename real>
+const char* render_kernel_name(const SceneView<real>&, uint32_t, bool, bool, uint32_t) { return ""; }
+template const char* render_kernel_name<double>(const SceneView<double>&, uint32_t, bool, bool, uint32_t);
+template const char* render_kernel_name<float>(const SceneView<float>&, uint32_t, bool, bool, uint32_t);
 }  // namespace rtk
 

@@ -34,11 +34,12 @@ def _assert_culling_counters(got, exact):
     """Work counters of a kernel that culls with CONSERVATIVE f32 boxes (the MIXED program) against the exact counters
     of the same hierarchy (oracle / f64-box kernel): everything a closest hit determines -- samples, segments, surface
     interactions, RNG draws -- is an equal integer; box and primitive tests can only be MORE (an enlarged box admits a
-    superset of rays, and an extra primitive test never produces a hit), by well under one per cent."""
+    superset of rays, and an extra primitive test never produces a hit), by about one per cent (C2 at full size: +0.66 %
+    box tests, +1.03 % sphere tests -- the 2^-19 x extent margin is 1 % of a radius-0.2 sphere's box)."""
     for key in ("samples", "segments", "surface_hits", "rng_draws", "quad_tests", "triangle_tests", "xform_enters", "medium_tests", "noise_calls", "texel_fetches"):
         assert got[key] == exact[key], key
     for key in ("box_tests", "sphere_tests"):
-        assert exact[key] <= got[key] <= exact[key] * 1.01 + 8, (key, got[key], exact[key])
+        assert exact[key] <= got[key] <= exact[key] * 1.02 + 8, (key, got[key], exact[key])
 
 
 @pytest.fixture(scope="module")
@@ -553,9 +554,13 @@ def test_render_multi_behind_the_c_abi_reproduces_the_one_gpu_bytes(rt, renderer
         seen = []
         multi.set_progress(lambda done, total: seen.append((done, total)), interval_ms=1)
         image, image8 = multi.render_host(cam, real_mode=mode)
+        first, seen = seen, []
+        multi.set_progress(lambda done, total: seen.append((done, total)), interval_ms=1)
         again, _ = multi.render_host(cam, real_mode=mode)       # buffers and the learned tile order are reused
         assert np.array_equal(image, whole) and np.array_equal(image8, whole8) and np.array_equal(again, whole)
-        assert seen and seen[-1][0] == seen[-1][1] > 0 and all(a[0] <= b[0] for a, b in zip(seen, seen[1:]))
+        for reports in (first, seen):     # per render: monotone, within [0, total], ending at the total (work items = tiles x sample chunks)
+            assert reports and reports[-1][0] == reports[-1][1] == -(-104 // len(devices)) * len(devices) * 2   # tiles per rank x ranks x 2 chunks
+            assert all(0 <= a[0] <= b[0] <= b[1] for a, b in zip(reports, reports[1:]))
         multi.close()
 
 

@@ -70,10 +70,13 @@ kernel_ms_profiled = sum(dur) / len(dur) if dur else None
 
 import bench  # noqa: E402  (kernel_source_hash)
 
+hash_file = os.path.join(out, "source_hash.txt")   # written at collection time (tools/pmc_collect.sh)
+source_hash = open(hash_file).read().strip() if os.path.exists(hash_file) else bench.kernel_source_hash()
+
 g = vals.get
 rec = {
     "config": cfg, "kernel": kernel, "workload": line["config"]["workload"].split("spp")[0], "n_gpus": 1, "dtype": "f64",
-    "order": line["config"]["order"], "source_hash": bench.kernel_source_hash(),
+    "order": line["config"]["order"], "source_hash": source_hash,
     "method": "rocprofv3 --pmc passes over `python3 bench.py --config %s ...` (tools/pmc_collect.sh), mean over the dispatches of the timed kernel; "
               "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B); durations from a separate --kernel-trace --stats run" % cfg,
     "counters": vals, "dispatches_averaged": n_disp, "kernel_ms_profiled": kernel_ms_profiled, "kernel_ms_bench_events": line["roofline"]["kernel_ms"],

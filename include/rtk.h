@@ -64,6 +64,9 @@ typedef enum rtk_node_kind {
     RTK_NODE_MEDIUM = 8      /* constant_medium.h:8-60 a = index into media[],     b = boundary node */
 } rtk_node_kind;
 
+/* For primitive nodes (sphere, quad, triangle) `c` is 0 or 1 + the primitive's rank in the reference's visiting
+ * order: rtk_scene_optimize fills it in so that, in its re-grouped hierarchy, two primitives hit at exactly the same
+ * distance are resolved the way the reference's left-then-right traversal resolves them. */
 typedef struct rtk_node { int32_t kind, a, b, c; } rtk_node;
 
 /* sphere.h:60-64: `ray center` (origin = center1, direction = center2-center1),

@@ -129,7 +129,26 @@ struct HitRec {  // hittable.h:11-27
     double t = 0;
     bool front_face = false;
     double u = 0, v = 0;
+    // not in the reference: which primitive produced the record -- its node kind and rtk_node.c (1 + rank in the
+    // reference's visiting order; 0 in reference-order descriptions).  Only read by the tie rule below.
+    int prim_kind = 0, rank = 0;
 };
+
+// ---- exact ties in a re-grouped hierarchy (rtk_scene_optimize output: primitive nodes carry rtk_node.c) ---------------
+// The reference resolves two primitives hit at exactly the same t by its visiting order: sphere::hit accepts a root only
+// strictly inside (tmin, tmax) (interval::surrounds, sphere.h:44-48), so the EARLIER sphere stays; quad::hit and
+// triangle::hit accept t == tmax (interval::contains, quad.h:39; `t > ray_t.max` rejects, triangle.h:91), so the LATER one
+// replaces it.  A re-grouped hierarchy visits in another order; with the reference ranks at hand the same outcome follows
+// from: a quad/triangle beats a sphere; among quads/triangles the higher rank wins; among spheres the lower rank.  `Tie`
+// says who set the tmax a test is called with.  In a reference-order description every rank is 0 and nothing changes.
+struct Tie {
+    int kind = 0, rank = 0;
+};
+inline Tie tie_of(const HitRec& rec) { return Tie{rec.prim_kind, rec.rank}; }
+inline bool strict_kind(int k) { return k == RTK_NODE_SPHERE; }
+inline bool inclusive_kind(int k) { return k == RTK_NODE_QUAD || k == RTK_NODE_TRIANGLE; }
+inline bool tie_sphere_wins(int my_rank, const Tie& best) { return my_rank != 0 && best.rank != 0 && strict_kind(best.kind) && my_rank < best.rank; }
+inline bool tie_inclusive_wins(int my_rank, const Tie& best) { return !inclusive_kind(best.kind) || my_rank == 0 || best.rank == 0 || my_rank > best.rank; }
 inline void set_face_normal(HitRec& rec, const Ray& r, V3 outward) {  // hittable.h:23-26
     rec.front_face = dot(r.d, outward) < 0;
     rec.normal = rec.front_face ? outward : -outward;
@@ -164,7 +183,7 @@ bool aabb_hit(const rtk_aabb& b, const Ray& r, double tmin, double tmax) {
 
 // ---------------------------------------------------------------- sphere --
 // sphere.h:32-58, 67-73.
-bool sphere_hit(const rtk_sphere& s, const Ray& r, double tmin, double tmax, HitRec& rec) {
+bool sphere_hit(const rtk_sphere& s, const Ray& r, double tmin, double tmax, HitRec& rec, int rank = 0, const Tie& best = Tie{}) {
     V3 current_center = v3(s.center0) + r.tm * v3(s.center_dir);  // center.at(r.time())
     V3 oc = current_center - r.o;
     double a = length_squared(r.d);
@@ -174,11 +193,14 @@ bool sphere_hit(const rtk_sphere& s, const Ray& r, double tmin, double tmax, Hit
     if (discriminant < 0) return false;
     double sqrtd = std::sqrt(discriminant);
     double root = (h - sqrtd) / a;
-    if (!(tmin < root && root < tmax)) {  // interval::surrounds
+    auto accepts = [&](double t) { return (tmin < t && t < tmax) /* interval::surrounds */ || (t == tmax && tmin < t && tie_sphere_wins(rank, best)); };
+    if (!accepts(root)) {
         root = (h + sqrtd) / a;
-        if (!(tmin < root && root < tmax)) return false;
+        if (!accepts(root)) return false;
     }
     rec.t = root;
+    rec.prim_kind = RTK_NODE_SPHERE;
+    rec.rank = rank;
     rec.p = at(r, rec.t);
     V3 outward = (rec.p - current_center) / s.radius;
     set_face_normal(rec, r, outward);
@@ -192,7 +214,7 @@ bool sphere_hit(const rtk_sphere& s, const Ray& r, double tmin, double tmax, Hit
 
 // ---------------------------------------------------------------- quad ----
 // quad.h:29-73.
-bool quad_hit(const rtk_quad& q, const Ray& r, double tmin, double tmax, HitRec& rec) {
+bool quad_hit(const rtk_quad& q, const Ray& r, double tmin, double tmax, HitRec& rec, int rank = 0, const Tie& best = Tie{}) {
     V3 normal = v3(q.normal);
     double denom = dot(normal, r.d);
     if (std::fabs(denom) < 1e-8) return false;
@@ -203,6 +225,9 @@ bool quad_hit(const rtk_quad& q, const Ray& r, double tmin, double tmax, HitRec&
     double alpha = dot(v3(q.w), cross(planar, v3(q.v)));
     double beta = dot(v3(q.w), cross(v3(q.u), planar));
     if (!(0 <= alpha && alpha <= 1) || !(0 <= beta && beta <= 1)) return false;  // is_interior
+    if (t == tmax && !tie_inclusive_wins(rank, best)) return false;                // (tie rule above; never in a reference-order description)
+    rec.prim_kind = RTK_NODE_QUAD;
+    rec.rank = rank;
     rec.u = alpha;
     rec.v = beta;
     rec.t = t;
@@ -215,7 +240,7 @@ bool quad_hit(const rtk_quad& q, const Ray& r, double tmin, double tmax, HitRec&
 // ---------------------------------------------------------------- triangle
 // triangle.h:65-122.  det, invDet, alpha, beta, gamma are `float` there
 // (triangle.h:72,77,96-98) and the UV mix is float arithmetic.
-bool triangle_hit(const rtk_triangle& tr, const Ray& r, double tmin, double tmax, HitRec& rec) {
+bool triangle_hit(const rtk_triangle& tr, const Ray& r, double tmin, double tmax, HitRec& rec, int rank = 0, const Tie& best = Tie{}) {
     V3 p0 = v3(tr.p0);
     V3 v0v1 = v3(tr.p1) - p0;
     V3 v0v2 = v3(tr.p2) - p0;
@@ -237,6 +262,9 @@ bool triangle_hit(const rtk_triangle& tr, const Ray& r, double tmin, double tmax
     float gamma = float(v);
     double da = alpha, db = beta;
     if (!(0 <= da && da <= 1) || !(0 <= db && db <= 1)) return false;  // is_interior(alpha, beta)
+    if (t == tmax && !tie_inclusive_wins(rank, best)) return false;     // (tie rule above)
+    rec.prim_kind = RTK_NODE_TRIANGLE;
+    rec.rank = rank;
     rec.u = alpha * tr.uv0[0] + beta * tr.uv1[0] + gamma * tr.uv2[0];
     rec.v = alpha * tr.uv0[1] + beta * tr.uv1[1] + gamma * tr.uv2[1];
     rec.t = t;
@@ -246,17 +274,20 @@ bool triangle_hit(const rtk_triangle& tr, const Ray& r, double tmin, double tmax
     return true;
 }
 
-bool node_hit(Ctx& cx, int node, const Ray& r, double tmin, double tmax, HitRec& rec);
+// `best` travels with tmax: the primitive whose hit set it (Tie{} when tmax is the caller's own bound).
+bool node_hit(Ctx& cx, int node, const Ray& r, double tmin, double tmax, HitRec& rec, const Tie& best = Tie{});
 
 // hittable_list.h:22-35.
-bool list_hit(Ctx& cx, const rtk_node& n, const Ray& r, double tmin, double tmax, HitRec& rec) {
+bool list_hit(Ctx& cx, const rtk_node& n, const Ray& r, double tmin, double tmax, HitRec& rec, const Tie& best) {
     HitRec temp_rec;
     bool hit_anything = false;
     double closest_so_far = tmax;
+    Tie closest = best;
     for (int i = 0; i < n.b; i++) {
-        if (node_hit(cx, cx.sc->list_children[n.a + i], r, tmin, closest_so_far, temp_rec)) {
+        if (node_hit(cx, cx.sc->list_children[n.a + i], r, tmin, closest_so_far, temp_rec, closest)) {
             hit_anything = true;
             closest_so_far = temp_rec.t;
+            closest = tie_of(temp_rec);
             rec = temp_rec;
         }
     }
@@ -264,30 +295,30 @@ bool list_hit(Ctx& cx, const rtk_node& n, const Ray& r, double tmin, double tmax
 }
 
 // bvh.h:64-72.
-bool bvh_hit(Ctx& cx, const rtk_node& n, const Ray& r, double tmin, double tmax, HitRec& rec) {
+bool bvh_hit(Ctx& cx, const rtk_node& n, const Ray& r, double tmin, double tmax, HitRec& rec, const Tie& best) {
     cx.cnt.box_tests++;
     if (!aabb_hit(cx.sc->bvh_boxes[n.c], r, tmin, tmax)) return false;
-    bool hit_left = node_hit(cx, n.a, r, tmin, tmax, rec);
-    bool hit_right = node_hit(cx, n.b, r, tmin, hit_left ? rec.t : tmax, rec);
+    bool hit_left = node_hit(cx, n.a, r, tmin, tmax, rec, best);
+    bool hit_right = node_hit(cx, n.b, r, tmin, hit_left ? rec.t : tmax, rec, hit_left ? tie_of(rec) : best);
     return hit_left || hit_right;
 }
 
 // hittable.h:46-58.
-bool translate_hit(Ctx& cx, const rtk_node& n, const Ray& r, double tmin, double tmax, HitRec& rec) {
+bool translate_hit(Ctx& cx, const rtk_node& n, const Ray& r, double tmin, double tmax, HitRec& rec, const Tie& best) {
     V3 offset = v3(cx.sc->translates[n.a].offset);
     Ray moved{r.o - offset, r.d, r.tm};
-    if (!node_hit(cx, n.b, moved, tmin, tmax, rec)) return false;
+    if (!node_hit(cx, n.b, moved, tmin, tmax, rec, best)) return false;
     rec.p = rec.p + offset;
     return true;
 }
 
 // hittable.h:101-139.
-bool rotate_y_hit(Ctx& cx, const rtk_node& n, const Ray& r, double tmin, double tmax, HitRec& rec) {
+bool rotate_y_hit(Ctx& cx, const rtk_node& n, const Ray& r, double tmin, double tmax, HitRec& rec, const Tie& best) {
     const double s = cx.sc->rotates[n.a].sin_theta, c = cx.sc->rotates[n.a].cos_theta;
     V3 origin = v3((c * r.o.x) - (s * r.o.z), r.o.y, (s * r.o.x) + (c * r.o.z));
     V3 direction = v3((c * r.d.x) - (s * r.d.z), r.d.y, (s * r.d.x) + (c * r.d.z));
     Ray rotated{origin, direction, r.tm};
-    if (!node_hit(cx, n.b, rotated, tmin, tmax, rec)) return false;
+    if (!node_hit(cx, n.b, rotated, tmin, tmax, rec, best)) return false;
     rec.p = v3((c * rec.p.x) + (s * rec.p.z), rec.p.y, (-s * rec.p.x) + (c * rec.p.z));
     rec.normal = v3((c * rec.normal.x) + (s * rec.normal.z), rec.normal.y, (-s * rec.normal.x) + (c * rec.normal.z));
     return true;
@@ -308,6 +339,8 @@ bool medium_hit(Ctx& cx, const rtk_node& n, const Ray& r, double tmin, double tm
     double hit_distance = m.neg_inv_density * std::log(rnd(cx.rng));
     if (hit_distance > distance_inside_boundary) return false;
     rec.t = rec1.t + hit_distance / ray_length;
+    rec.prim_kind = RTK_NODE_MEDIUM;
+    rec.rank = 0;
     rec.p = at(r, rec.t);
     rec.normal = v3(1, 0, 0);
     rec.front_face = true;
@@ -315,16 +348,16 @@ bool medium_hit(Ctx& cx, const rtk_node& n, const Ray& r, double tmin, double tm
     return true;
 }
 
-bool node_hit(Ctx& cx, int node, const Ray& r, double tmin, double tmax, HitRec& rec) {
+bool node_hit(Ctx& cx, int node, const Ray& r, double tmin, double tmax, HitRec& rec, const Tie& best) {
     const rtk_node& n = cx.sc->nodes[node];
     switch (n.kind) {
-        case RTK_NODE_SPHERE: cx.cnt.sphere_tests++; return sphere_hit(cx.sc->spheres[n.a], r, tmin, tmax, rec);
-        case RTK_NODE_QUAD: cx.cnt.quad_tests++; return quad_hit(cx.sc->quads[n.a], r, tmin, tmax, rec);
-        case RTK_NODE_TRIANGLE: cx.cnt.triangle_tests++; return triangle_hit(cx.sc->triangles[n.a], r, tmin, tmax, rec);
-        case RTK_NODE_LIST: return list_hit(cx, n, r, tmin, tmax, rec);
-        case RTK_NODE_BVH: return bvh_hit(cx, n, r, tmin, tmax, rec);
-        case RTK_NODE_TRANSLATE: cx.cnt.xform_enters++; return translate_hit(cx, n, r, tmin, tmax, rec);
-        case RTK_NODE_ROTATE_Y: cx.cnt.xform_enters++; return rotate_y_hit(cx, n, r, tmin, tmax, rec);
+        case RTK_NODE_SPHERE: cx.cnt.sphere_tests++; return sphere_hit(cx.sc->spheres[n.a], r, tmin, tmax, rec, n.c, best);
+        case RTK_NODE_QUAD: cx.cnt.quad_tests++; return quad_hit(cx.sc->quads[n.a], r, tmin, tmax, rec, n.c, best);
+        case RTK_NODE_TRIANGLE: cx.cnt.triangle_tests++; return triangle_hit(cx.sc->triangles[n.a], r, tmin, tmax, rec, n.c, best);
+        case RTK_NODE_LIST: return list_hit(cx, n, r, tmin, tmax, rec, best);
+        case RTK_NODE_BVH: return bvh_hit(cx, n, r, tmin, tmax, rec, best);
+        case RTK_NODE_TRANSLATE: cx.cnt.xform_enters++; return translate_hit(cx, n, r, tmin, tmax, rec, best);
+        case RTK_NODE_ROTATE_Y: cx.cnt.xform_enters++; return rotate_y_hit(cx, n, r, tmin, tmax, rec, best);
         case RTK_NODE_MEDIUM: cx.cnt.medium_tests++; return medium_hit(cx, n, r, tmin, tmax, rec);
     }
     return false;

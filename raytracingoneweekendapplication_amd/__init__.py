@@ -363,6 +363,12 @@ class Renderer:
                 "n_bvh_nodes_in": info.n_bvh_nodes_in, "n_bvh_nodes_out": info.n_bvh_nodes_out,
                 "expected_cost": info.expected_cost, "box_margin": info.box_margin}
 
+    def upload_optimized(self, scene, eye: Optional[Vec3] = None) -> None:
+        """rtk_scene_upload_optimized: a description that already IS a re-grouped hierarchy (rtk_scene_optimize output, or a
+        hand-built one whose primitive nodes carry reference ranks in rtk_node.c), with the fast-order kernels."""
+        opts = OptimizeOpts(1 if eye is not None else 0, 0, eye if eye is not None else Vec3(0, 0, 0), 0.0)
+        self._check(self._lib.rtk_scene_upload_optimized(self._ctx, scene.desc_ptr, C.byref(opts)))
+
     def scene_info(self) -> dict:
         n, b64, b32 = C.c_int32(), C.c_int64(), C.c_int64()
         self._check(self._lib.rtk_scene_info(self._ctx, C.byref(n), C.byref(b64), C.byref(b32)))

@@ -65,6 +65,7 @@ using Chain = std::vector<ChainStep>;
 
 struct Program {
     std::vector<Op> ops;
+    std::vector<uint32_t> ranks;  // parallel to ops: rtk_node.c of a primitive op (1 + reference visiting rank; 0 = none)
     std::vector<Chain> chains;
     std::map<Chain, uint32_t> chain_ids;
     size_t last_label = size_t(-1);  // op index some skip link points at
@@ -97,8 +98,9 @@ struct Compiler {
         prog.chain_ids[c] = id;
         return id;
     }
-    uint32_t push(uint32_t kind, uint32_t payload, uint32_t aux) {
+    uint32_t push(uint32_t kind, uint32_t payload, uint32_t aux, uint32_t rank = 0) {
         prog.ops.push_back(Op{make_op(kind, payload), aux});
+        prog.ranks.push_back(rank);
         return uint32_t(prog.ops.size()) - 1;
     }
     void label_here() { prog.last_label = prog.ops.size(); }
@@ -124,18 +126,18 @@ struct Compiler {
         switch (n.kind) {
             case RTK_NODE_SPHERE:
                 if (n.a < 0 || n.a >= sc.n_spheres) return bad(RTK_ERR_INVALID, "sphere index out of range");
-                push(OP_SPHERE, uint32_t(n.a), cid);
+                push(OP_SPHERE, uint32_t(n.a), cid, n.c > 0 ? uint32_t(n.c) : 0u);
                 prog.n_primitive_ops++;
                 return true;
             case RTK_NODE_QUAD:
                 if (n.a < 0 || n.a >= sc.n_quads) return bad(RTK_ERR_INVALID, "quad index out of range");
-                push(OP_QUAD, uint32_t(n.a), cid);
+                push(OP_QUAD, uint32_t(n.a), cid, n.c > 0 ? uint32_t(n.c) : 0u);
                 prog.features |= F_QUAD;
                 prog.n_primitive_ops++;
                 return true;
             case RTK_NODE_TRIANGLE:
                 if (n.a < 0 || n.a >= sc.n_triangles) return bad(RTK_ERR_INVALID, "triangle index out of range");
-                push(OP_TRI, uint32_t(n.a), cid);
+                push(OP_TRI, uint32_t(n.a), cid, n.c > 0 ? uint32_t(n.c) : 0u);
                 prog.features |= F_TRI;
                 prog.n_primitive_ops++;
                 return true;
@@ -290,7 +292,8 @@ inline float round_up(double x) {
 // float(o): |b*inv| 2^-22.4 + |o*inv| 2^-22 + |t| 2^-24, i.e. a plane displaced by less than 2^-21 (|b| + |o|)
 // <= 2^-20 x extent -- half the margin.  The kernel sends rays whose origin leaves [-extent, extent]^3 through the
 // exact test instead (they cannot come from a surface of the scene).
-static void build_mixed_program(const rtk_scene_desc& sc, const Program& prog, double eye_extent, std::vector<MixedHead>& units, float& extent_out) {
+static void build_mixed_program(const rtk_scene_desc& sc, const Program& prog, double eye_extent, std::vector<MixedHead>& units, std::vector<uint32_t>& rank_of_unit,
+                                float& extent_out) {
     auto kind_of = [&](const Op& op) -> uint32_t {
         uint32_t kind = op.kind_payload & 15u;
         if (kind == OP_SPHERE) {
@@ -317,12 +320,14 @@ static void build_mixed_program(const rtk_scene_desc& sc, const Program& prog, d
     const double margin = std::ldexp(extent, -19);  // (A/B on C2: a margin 128 times smaller renders 0.7 % faster -- nothing to gain)
     units.assign(unit_of_op.back(), MixedHead{});
     std::memset(units.data(), 0, units.size() * sizeof(MixedHead));
+    rank_of_unit.assign(unit_of_op.back(), 0u);
     for (size_t i = 0; i < prog.ops.size(); i++) {
         const Op& op = prog.ops[i];
         const uint32_t kind = kind_of(op), payload = op.kind_payload >> 4;
         MixedHead* rec = &units[unit_of_op[i]];
         rec->kind_payload = make_op(kind, payload);
         rec->aux = op.aux;
+        rank_of_unit[unit_of_op[i]] = prog.ranks[i];
         if (kind == OP_BOX) {
             const rtk_aabb& b = sc.bvh_boxes[payload];
             rec->f[0] = round_down(b.xmin - margin); rec->f[1] = round_up(b.xmax + margin);
@@ -346,8 +351,117 @@ static void build_mixed_program(const rtk_scene_desc& sc, const Program& prog, d
     extent_out = float(extent);
 }
 
+// Largest coordinate magnitude the f32 culling boxes of a scene have to cope with: every box bound and primitive
+// extent (each in its own space), every instance offset, the eye.
+static double scene_extent(const rtk_scene_desc& sc, double eye_extent) {
+    double e = eye_extent;
+    auto take = [&](double v) { e = std::max(e, std::fabs(v)); };
+    for (int32_t i = 0; i < sc.n_bvh_boxes; i++) {
+        const rtk_aabb& b = sc.bvh_boxes[i];
+        for (double v : {b.xmin, b.xmax, b.ymin, b.ymax, b.zmin, b.zmax}) take(v);
+    }
+    for (int32_t i = 0; i < sc.n_spheres; i++) {
+        const rtk_sphere& s = sc.spheres[i];
+        for (double c : {s.center0.x, s.center0.y, s.center0.z, s.center0.x + s.center_dir.x, s.center0.y + s.center_dir.y, s.center0.z + s.center_dir.z})
+            e = std::max(e, std::fabs(c) + std::fabs(s.radius));
+    }
+    for (int32_t i = 0; i < sc.n_quads; i++) {
+        const rtk_quad& q = sc.quads[i];
+        for (int k = 0; k < 4; k++) {
+            const double a = (k & 1) ? 1.0 : 0.0, b = (k & 2) ? 1.0 : 0.0;
+            take(q.Q.x + a * q.u.x + b * q.v.x); take(q.Q.y + a * q.u.y + b * q.v.y); take(q.Q.z + a * q.u.z + b * q.v.z);
+        }
+    }
+    for (int32_t i = 0; i < sc.n_triangles; i++) {
+        const rtk_triangle& t = sc.triangles[i];
+        for (const rtk_vec3* p : {&t.p0, &t.p1, &t.p2}) { take(p->x); take(p->y); take(p->z); }
+    }
+    double offsets = 0;  // a ray's origin in an instance's space is at most this far beyond its world-space position
+    for (int32_t i = 0; i < sc.n_translates; i++)
+        offsets = std::max(offsets, std::max(std::fabs(sc.translates[i].offset.x), std::max(std::fabs(sc.translates[i].offset.y), std::fabs(sc.translates[i].offset.z))));
+    return (e + offsets * double(kMaxChain)) * (sc.n_rotates > 0 ? 1.5 : 1.0);  // a rotation about y mixes x and z: sqrt(2) < 1.5
+}
+
+// The COMPACT program of rtk_device_layout.h for any scene whose boxes carry rtk_scene_optimize's margin: f32 culling
+// boxes exactly as in build_mixed_program (rounded outward, grown by 2^-19 of the extent; same error budget -- under an
+// instance transform the kernel applies it to the object-space ray and sends a ray whose object-space origin leaves
+// [-extent, extent]^3 through the exact test), every primitive in f64, 16-byte units.
+static void build_compact_program(const rtk_scene_desc& sc, const Program& prog, double eye_extent, std::vector<Unit16>& units, std::vector<uint32_t>& rank_of_unit,
+                                  float& extent_out) {
+    auto kind_of = [&](const Op& op) -> uint32_t {
+        uint32_t kind = op.kind_payload & 15u;
+        if (kind == OP_SPHERE) {
+            const rtk_sphere& s = sc.spheres[op.kind_payload >> 4];
+            if (s.center_dir.x != 0 || s.center_dir.y != 0 || s.center_dir.z != 0) kind = OP_SPHERE_MOVING;
+        }
+        return kind;
+    };
+    std::vector<uint32_t> unit_of_op(prog.ops.size() + 1, 0);
+    for (size_t i = 0; i < prog.ops.size(); i++) unit_of_op[i + 1] = unit_of_op[i] + uint32_t(compact_units(kind_of(prog.ops[i])));
+    const double extent = double(round_up(scene_extent(sc, eye_extent) * 1.0000001));
+    const double margin = std::ldexp(extent, -19);
+    units.assign(unit_of_op.back(), Unit16{{0u, 0u, 0u, 0u}});
+    rank_of_unit.assign(unit_of_op.back(), 0u);
+    for (size_t i = 0; i < prog.ops.size(); i++) {
+        const Op& op = prog.ops[i];
+        const uint32_t kind = kind_of(op), payload = op.kind_payload >> 4;
+        MixedHead* head = reinterpret_cast<MixedHead*>(&units[unit_of_op[i]]);
+        double* more = reinterpret_cast<double*>(&units[unit_of_op[i]]) + 4;  // payload element 3 onwards (byte 32)
+        head->kind_payload = make_op(kind, payload);
+        head->aux = op.aux;
+        rank_of_unit[unit_of_op[i]] = prog.ranks[i];
+        auto with_material = [&](int32_t material) { head->aux = (op.aux & 255u) | (uint32_t(material) << 8); };
+        switch (kind) {
+            case OP_BOX: {
+                const rtk_aabb& b = sc.bvh_boxes[payload];
+                head->f[0] = round_down(b.xmin - margin); head->f[1] = round_up(b.xmax + margin);
+                head->f[2] = round_down(b.ymin - margin); head->f[3] = round_up(b.ymax + margin);
+                head->f[4] = round_down(b.zmin - margin); head->f[5] = round_up(b.zmax + margin);
+                head->aux = unit_of_op[op.aux];
+                break;
+            }
+            case OP_SPHERE:
+            case OP_SPHERE_MOVING: {
+                const rtk_sphere& s = sc.spheres[payload];
+                head->d[0] = s.center0.x; head->d[1] = s.center0.y; head->d[2] = s.center0.z;
+                more[0] = s.radius;
+                more[1] = 1.0 / s.radius;  // the factor of `(p - center) / radius` (vec3.h:91-93), once instead of per hit
+                if (kind == OP_SPHERE_MOVING) { more[2] = s.center_dir.x; more[3] = s.center_dir.y; more[4] = s.center_dir.z; }
+                with_material(s.material);
+                break;
+            }
+            case OP_QUAD: {
+                const rtk_quad& q = sc.quads[payload];
+                const double vals[16] = {q.normal.x, q.normal.y, q.normal.z, q.D, q.Q.x, q.Q.y, q.Q.z, q.w.x, q.w.y, q.w.z,
+                                         q.v.x, q.v.y, q.v.z, q.u.x, q.u.y, q.u.z};
+                for (int e = 0; e < 3; e++) head->d[e] = vals[e];
+                for (int e = 3; e < 16; e++) more[e - 3] = vals[e];
+                with_material(q.material);
+                break;
+            }
+            case OP_TRI: {
+                const rtk_triangle& t = sc.triangles[payload];
+                // v0v1 = p1 - p0, v0v2 = p2 - p0 (triangle.h:67-68) in double
+                const double vals[9] = {t.p2.x - t.p0.x, t.p2.y - t.p0.y, t.p2.z - t.p0.z, t.p1.x - t.p0.x, t.p1.y - t.p0.y, t.p1.z - t.p0.z,
+                                        t.p0.x, t.p0.y, t.p0.z};
+                for (int e = 0; e < 3; e++) head->d[e] = vals[e];
+                for (int e = 3; e < 9; e++) more[e - 3] = vals[e];
+                with_material(t.material);
+                break;
+            }
+            case OP_MED_MID: head->aux = unit_of_op[op.aux]; break;
+            case OP_MED_END:
+                head->d[0] = sc.media[payload].neg_inv_density;
+                with_material(sc.media[payload].material);
+                break;
+            default: break;
+        }
+    }
+    extent_out = float(extent);
+}
+
 template <typename real>
-int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScene<real>& out, bool want_mixed = false, double eye_extent = 0.0) {
+int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScene<real>& out, bool fast_order = false, bool want_mixed = false, double eye_extent = 0.0) {
     out.release();
     // ---- the fused traversal program: one or more slots per op, skip links
     // translated from op indices to slot indices
@@ -565,12 +679,69 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
             out.view.n_rank_words = int32_t(rank.size());
         }
     }
+    out.view.program_compact = nullptr;
+    out.view.n_units16 = 0;
+    out.view.tie_rank = nullptr;
+    out.view.tie_rank_slot = nullptr;
+    out.view.box_cache16 = nullptr;
+    out.view.kind_words16 = nullptr;
+    out.view.box_rank16 = nullptr;
+    out.view.n_cached_boxes16 = out.view.n_kind_words16 = out.view.n_rank_words16 = 0;
+    if (fast_order) {  // reference ranks of the primitive records, for exact ties (see SceneView::tie_rank)
+        std::vector<uint32_t> rank_of_slot(slots.size(), 0u);
+        bool any = false;
+        for (size_t i = 0; i < prog.ops.size(); i++) {
+            rank_of_slot[slot_of_op[i]] = prog.ranks[i];
+            any = any || prog.ranks[i] != 0;
+        }
+        if (any && (rc = out.upload(rank_of_slot, &out.view.tie_rank_slot)) != RTK_OK) return rc;
+    }
     if constexpr (sizeof(real) == 8) {
-        if (want_mixed) {
+        if (fast_order && want_mixed) {
             std::vector<MixedHead> units;
-            build_mixed_program(sc, prog, eye_extent, units, out.view.extent);
+            std::vector<uint32_t> ranks;
+            build_mixed_program(sc, prog, eye_extent, units, ranks, out.view.extent);
             if ((rc = out.upload(units, &out.view.program_mixed)) != RTK_OK) return rc;
+            if ((rc = out.upload(ranks, &out.view.tie_rank)) != RTK_OK) return rc;
             out.view.n_units = int32_t(units.size());
+        } else if (fast_order) {
+            std::vector<Unit16> units;
+            std::vector<uint32_t> ranks;
+            build_compact_program(sc, prog, eye_extent, units, ranks, out.view.extent);
+            if ((rc = out.upload(units, &out.view.program_compact)) != RTK_OK) return rc;
+            if ((rc = out.upload(ranks, &out.view.tie_rank)) != RTK_OK) return rc;
+            out.view.n_units16 = int32_t(units.size());
+            // too large for LDS: the box heads alone, with the tables that find them (F_LDS_BOXES on the COMPACT program)
+            if (units.size() * sizeof(Unit16) + mats.size() * sizeof(MaterialRec<real>) > size_t(kLdsBytesPerCU)) {
+                std::vector<MixedHead> boxes;
+                std::vector<uint32_t> kind_words((units.size() + 7) / 8, 0u);
+                std::vector<uint2> rank((units.size() + 31) / 32, uint2{0u, 0u});
+                for (size_t pc = 0; pc < units.size();) {
+                    const MixedHead* head = reinterpret_cast<const MixedHead*>(&units[pc]);
+                    const uint32_t kind = head->kind_payload & 15u;
+                    kind_words[pc >> 3] |= kind << ((pc & 7) * 4);
+                    if (kind == OP_BOX) {
+                        rank[pc >> 5].x |= 1u << (pc & 31);
+                        boxes.push_back(*head);
+                    }
+                    pc += size_t(compact_units(kind));
+                }
+                uint32_t before = 0;
+                for (auto& r : rank) {
+                    r.y = before;
+                    before += uint32_t(__builtin_popcount(r.x));
+                }
+                const size_t bytes = boxes.size() * sizeof(MixedHead) + ((kind_words.size() * 4 + 7) & ~size_t(7)) + rank.size() * 8;
+                if (getenv("RTK_DEBUG")) fprintf(stderr, "[rtk] COMPACT program: %zu units (%zu B), %zu boxes, boxes + tables %zu B\n", units.size(), units.size() * 16, boxes.size(), bytes);
+                if (!boxes.empty() && bytes + 64 <= size_t(kLdsBytesPerCU)) {
+                    if ((rc = out.upload(boxes, &out.view.box_cache16)) != RTK_OK) return rc;
+                    if ((rc = out.upload(kind_words, &out.view.kind_words16)) != RTK_OK) return rc;
+                    if ((rc = out.upload(rank, &out.view.box_rank16)) != RTK_OK) return rc;
+                    out.view.n_cached_boxes16 = int32_t(boxes.size());
+                    out.view.n_kind_words16 = int32_t(kind_words.size());
+                    out.view.n_rank_words16 = int32_t(rank.size());
+                }
+            }
         }
     }
     return RTK_OK;
@@ -815,6 +986,7 @@ static int compile_scene(const rtk_scene_desc* scene, Program& prog) {
     if (prog.error_code != RTK_OK) return fail(prog.error_code, "rtk_scene_upload: %s", prog.error.c_str());
     if (prog.n_primitive_ops == 0) return fail(RTK_ERR_INVALID, "rtk_scene_upload: no primitive reachable from the root");
     prog.ops.push_back(Op{make_op(OP_END, 0), 0});
+    prog.ranks.push_back(0);
     return RTK_OK;
 }
 
@@ -850,9 +1022,11 @@ static int upload_scene(rtk_ctx* ctx, const rtk_scene_desc* scene, uint32_t hier
     ctx->has_scene = false;
     ctx->order_valid = false;  // a new scene: tile costs measured on the old one mean nothing
     // sphere-only scenes in the fast order additionally get the MIXED program (f32 culling boxes) for the f64 kernels
-    const bool want_mixed = (hierarchy_flags & F_FMA_BOX) != 0 && prog.features == kFeatLean && prog.chains.size() <= 1;
-    if ((rc = build_device_scene<double>(*scene, prog, ctx->scene64, want_mixed, eye_extent)) != RTK_OK) return rc;
-    if ((rc = build_device_scene<float>(*scene, prog, ctx->scene32)) != RTK_OK) return rc;
+    // ... every other scene of the fast order the COMPACT program (f32 culling boxes, f64 primitives, 16-byte units)
+    const bool fast_order = (hierarchy_flags & F_FMA_BOX) != 0;
+    const bool want_mixed = fast_order && prog.features == kFeatLean && prog.chains.size() <= 1;
+    if ((rc = build_device_scene<double>(*scene, prog, ctx->scene64, fast_order, want_mixed, eye_extent)) != RTK_OK) return rc;
+    if ((rc = build_device_scene<float>(*scene, prog, ctx->scene32, fast_order)) != RTK_OK) return rc;
     ctx->features = prog.features | hierarchy_flags;
     ctx->n_ops = int32_t(prog.ops.size());
     ctx->has_scene = true;

@@ -94,6 +94,24 @@ struct alignas(16) MixedHead {
 static_assert(sizeof(MixedHead) == 32, "mixed unit size");
 inline constexpr int mixed_units(uint32_t kind) { return kind == OP_SPHERE ? 2 : (kind == OP_SPHERE_MOVING ? 3 : 1); }
 
+// The COMPACT traversal program: the MIXED idea for EVERY scene of the fast order (f64 kernels) -- f32 culling boxes, exact
+// f64 primitives -- with records packed in 16-byte units (pc counts units) so that a triangle costs 80 bytes instead of
+// 128 and the C4 mesh program (1 334 boxes + 1 280 triangles: 151 KB) fits one CU's LDS whole.  Every record starts
+// with a MixedHead (24 payload bytes, then {kind_payload, aux} at bytes 24..31); further payload follows as doubles:
+// element e of a record's payload is head.d[e] for e < 3 and the double at byte 32 + 8 (e - 3) otherwise.
+//   OP_BOX            2 units: f[0..5] as in the MIXED program; aux = pc to continue at when the slab test fails
+//   OP_SPHERE         3 units: centre(3), radius, 1/radius
+//   OP_SPHERE_MOVING  5 units: centre(3), radius, 1/radius, centre2 - centre1 (3)
+//   OP_QUAD           9 units: n(3), D, Q(3), w(3), v(3), u(3)
+//   OP_TRI            5 units: e2(3), e1(3), p0(3)
+//   OP_CHAIN, OP_MED_BEGIN, OP_MED_MID, OP_MED_END (element 0 = neg_inv_density), OP_END: 2 units
+struct alignas(16) Unit16 {
+    uint32_t w[4];
+};
+inline constexpr int compact_units(uint32_t kind) {
+    return kind == OP_SPHERE ? 3 : (kind == OP_SPHERE_MOVING ? 5 : (kind == OP_QUAD ? 9 : (kind == OP_TRI ? 5 : 2)));
+}
+
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 constexpr int kMaxChain = 4;
 constexpr int kMaxChunks = 64;
@@ -195,6 +213,17 @@ struct SceneView {  // device pointers, passed to the kernel by value
     const MixedHead* program_mixed;
     int32_t n_units;
     float extent;
+    // COMPACT program (F_F32_BOX kernels of the other families; null when the scene has a MIXED program or was uploaded in
+    // the reference order) -- same `extent` rule, applied to the object-space origin under instance transforms
+    const Unit16* program_compact;
+    int32_t n_units16;
+    // Fast-order uploads: rank of the primitive record at pc in the REFERENCE's visiting order (rtk_node.c), indexed by the
+    // pc of the f32-box program (MIXED units or COMPACT units) resp. of the slot program; 0 = unknown.  Only read when two
+    // primitives are hit at exactly the same distance, to resolve the tie the way the reference's left-to-right
+    // traversal does (strict `surrounds` for spheres, sphere.h:44-48; inclusive `contains` for quads and triangles,
+    // quad.h:39, triangle.h:91).  Null in reference-order uploads: there the visiting order itself is the reference's.
+    const uint32_t* tie_rank;
+    const uint32_t* tie_rank_slot;
     // F_LDS_BOXES (programs larger than LDS; null when the program fits or the boxes do not): the OP_BOX slots in program
     // order; kind_words[pc >> 3] holds the kind of slot pc in nibble (pc & 7); box_rank[pc >> 5] = {bit per slot that
     // starts a box, number of boxes before slot 32 * (pc >> 5)} -- cache index of the box at pc = y + popc(x & below(pc)).
@@ -202,6 +231,12 @@ struct SceneView {  // device pointers, passed to the kernel by value
     const uint32_t* kind_words;
     const uint2* box_rank;
     int32_t n_cached_boxes, n_kind_words, n_rank_words;
+    // ... and the same three tables for a COMPACT program larger than LDS: its box heads (32 bytes each), kind nibbles and
+    // rank words per 16-byte unit
+    const MixedHead* box_cache16;
+    const uint32_t* kind_words16;
+    const uint2* box_rank16;
+    int32_t n_cached_boxes16, n_kind_words16, n_rank_words16;
 };
 
 struct TileMap {  // which tiles this launch renders and where the pixels go

@@ -110,6 +110,7 @@ struct Optimizer {
     std::vector<double> memo_cost;
     std::vector<char> on_stack;
     std::vector<char> memo_media;    // the subtree of that input node contains a constant_medium
+    std::vector<int32_t> ref_rank;   // input primitive node -> 1 + rank of its first visit in the reference order (0: never visited)
     bool failed = false;
     bool has_media = false;
     double margin = 0.0, tri_margin = 0.0;
@@ -239,7 +240,7 @@ struct Optimizer {
                     break;
                 }
                 cost = prim_cost(n.kind);
-                o = push_node(n.kind, n.a, n.b, n.c);
+                o = push_node(n.kind, n.a, n.b, ref_rank[size_t(node)]);  // c = 1 + rank in the reference's visiting order (tie-break)
                 break;
             case RTK_NODE_LIST:
             case RTK_NODE_BVH: {
@@ -502,6 +503,34 @@ struct Optimizer {
 
     // Scene extent for the rounding margin: boxes of all primitives in their own spaces plus the transforms'
     // offsets are bounded by the root box and the object-space boxes; use the largest coordinate seen.
+    // The reference's visiting order of the INPUT graph: hittable_list children in order (hittable_list.h:29-33), a
+    // bvh_node's left then right (bvh.h:68-69), a transform's child, a medium's boundary.  Iterative (graphs from
+    // files may be deep); a node reached again keeps the rank of its first visit.
+    void compute_ranks(int32_t root) {
+        ref_rank.assign(size_t(in.n_nodes), 0);
+        std::vector<char> seen(size_t(in.n_nodes), 0);
+        std::vector<int32_t> stack{root};
+        int32_t next = 1;
+        size_t guard = 0;
+        while (!stack.empty() && guard++ < (size_t(1) << 26)) {
+            const int32_t node = stack.back();
+            stack.pop_back();
+            if (node < 0 || node >= in.n_nodes || seen[size_t(node)]) continue;
+            seen[size_t(node)] = 1;
+            const rtk_node& n = in.nodes[node];
+            switch (n.kind) {
+                case RTK_NODE_SPHERE: case RTK_NODE_QUAD: case RTK_NODE_TRIANGLE: ref_rank[size_t(node)] = next++; break;
+                case RTK_NODE_LIST:
+                    if (n.a >= 0 && n.b >= 0 && int64_t(n.a) + n.b <= in.n_list_children)
+                        for (int32_t k = n.b; k-- > 0;) stack.push_back(in.list_children[n.a + k]);  // reversed: popped in list order
+                    break;
+                case RTK_NODE_BVH: stack.push_back(n.b); stack.push_back(n.a); break;
+                case RTK_NODE_TRANSLATE: case RTK_NODE_ROTATE_Y: case RTK_NODE_MEDIUM: stack.push_back(n.b); break;
+                default: break;
+            }
+        }
+    }
+
     void compute_margin() {
         double extent = 0;
         for (int32_t i = 0; i < in.n_nodes; i++) {
@@ -536,6 +565,7 @@ int rtk_scene_optimize(const rtk_scene_desc* scene, const rtk_optimize_opts* opt
     Holder* h = new (std::nothrow) Holder;
     if (!h) return RTK_ERR_INVALID;
     Optimizer op(*scene, opts, *h);
+    op.compute_ranks(scene->root);
     op.compute_margin();
     Box box;
     double cost = 0;
@@ -574,7 +604,9 @@ int rtk_scene_optimize(const rtk_scene_desc* scene, const rtk_optimize_opts* opt
     h->desc.n_bvh_boxes = int32_t(h->boxes.size());
     h->desc.bvh_boxes = h->boxes.data();
     if (info) {
-        info->exact = (op.has_media || op.has_triangles) ? 0 : 1;
+        // Closest hits are preserved and exact ties are resolved by the reference's ranks (rtk_node.c), so without a medium
+        // the image is the reference order's bit for bit; has_triangles flags the one caveat left (see rtk.h)
+        info->exact = op.has_media ? 0 : 1;
         info->has_media = op.has_media ? 1 : 0;
         info->has_triangles = op.has_triangles ? 1 : 0;
         info->n_bvh_nodes_in = int32_t(op.n_bvh_in);

@@ -234,15 +234,30 @@ RTK_DEV bool slab_test(const Slot<real>& b, V3<real> o, V3<real> inv, real tmin,
     return tmax > tmin;
 }
 
-// Element e of a primitive whose reals are packed over consecutive slots.
+// Element e of a primitive whose reals are packed over consecutive slots ...
 template <typename real, int E>
 RTK_DEV real packed(const Slot<real>* rec) {
     return rec[E / Slot<real>::kReals].v[E % Slot<real>::kReals];
 }
+// ... or over the 16-byte units of a COMPACT record: elements 0..2 in the head, the header at bytes 24..31, element
+// e >= 3 at byte 32 + 8 (e - 3) (rtk_device_layout.h).
 template <typename real, int E>
-RTK_DEV V3<real> packed3(const Slot<real>* rec) {
+RTK_DEV real packed(const Unit16* rec) {
+    return real(reinterpret_cast<const double*>(rec)[E < 3 ? E : E + 1]);
+}
+template <typename real, int E, typename Rec>
+RTK_DEV V3<real> packed3(const Rec* rec) {
     return V3<real>{packed<real, E>(rec), packed<real, E + 1>(rec), packed<real, E + 2>(rec)};
 }
+// Header words, record length and the few fields whose position differs between the two layouts.
+template <typename real> RTK_DEV uint32_t rec_kind_payload(const Slot<real>* rec) { return rec->kind_payload; }
+template <typename real> RTK_DEV uint32_t rec_kind_payload(const Unit16* rec) { return rec[1].w[2]; }
+template <typename real> RTK_DEV uint32_t rec_aux(const Slot<real>* rec) { return rec->aux; }
+template <typename real> RTK_DEV uint32_t rec_aux(const Unit16* rec) { return rec[1].w[3]; }
+template <typename real> RTK_DEV uint32_t rec_units(const Slot<real>*, uint32_t kind) { return uint32_t(slots_of<real>(kind)); }
+template <typename real> RTK_DEV uint32_t rec_units(const Unit16*, uint32_t kind) { return uint32_t(compact_units(kind)); }
+template <typename real> RTK_DEV V3<real> moving_dir(const Slot<real>* rec) { return mk(rec[1].v[0], rec[1].v[1], rec[1].v[2]); }   // centre2 - centre1 of a moving sphere
+template <typename real> RTK_DEV V3<real> moving_dir(const Unit16* rec) { return packed3<real, 5>(rec); }
 
 // n / a, correctly rounded, from y = RN(1/a) (computed once per segment by a true division): q0 = RN(n*y) is within
 // one ulp of the quotient, r = n - a*q0 is exact in one fused multiply-add, and q0 + r*y rounds to RN(n/a)
@@ -257,9 +272,33 @@ RTK_DEV real divide_by(real n, real a, real inv_a) {
     return rt_fma(r, inv_a, q0);
 }
 
+// ---- exact ties (fast-order kernels) ---------------------------------------------------------------------------------
+// Two primitives hit at EXACTLY the same distance: the reference resolves it by its visiting order -- a sphere accepts a
+// root only strictly inside (tmin, closest so far) (sphere.h:44-48), so of two spheres the EARLIER one stays; a quad or a
+// triangle accepts t == closest so far (quad.h:39, triangle.h:91), so the LATER one replaces whatever was there.  In a
+// re-grouped hierarchy the visiting order is another one; the records carry their rank in the reference's order
+// (SceneView::tie_rank, from rtk_node.c) and the same outcome is reproduced from the ranks: a quad/triangle beats a sphere,
+// the higher rank wins among quads/triangles, the lower rank among spheres.  The tables are touched only when a tie
+// actually occurs.  Unknown ranks (0, or no table) leave the decision to the visiting order, as before.
+RTK_DEV bool is_strict_kind(uint32_t k) { return k == OP_SPHERE || k == OP_SPHERE_MOVING; }
+RTK_DEV bool is_inclusive_kind(uint32_t k) { return k == OP_QUAD || k == OP_TRI; }
+// a sphere's root equals the closest distance so far: does the sphere take the hit over?
+RTK_DEV bool tie_sphere_wins(const uint32_t* __restrict__ ranks, uint32_t pc, uint32_t best_pc, uint32_t best_kind) {
+    if (!ranks || best_pc == kNoHit || !is_strict_kind(best_kind)) return false;
+    const uint32_t mine = ranks[pc], theirs = ranks[best_pc];
+    return mine != 0 && theirs != 0 && mine < theirs;
+}
+// a quad's / triangle's t equals the closest distance so far (which its inclusive test admits): does it take the hit over?
+RTK_DEV bool tie_inclusive_wins(const uint32_t* __restrict__ ranks, uint32_t pc, uint32_t best_pc, uint32_t best_kind) {
+    if (!ranks || best_pc == kNoHit || !is_inclusive_kind(best_kind)) return true;
+    const uint32_t mine = ranks[pc], theirs = ranks[best_pc];
+    return mine == 0 || theirs == 0 || mine > theirs;
+}
+
 // sphere::hit up to the accepted root (sphere.h:32-49); cc = center.at(r.time()); a = d.d, inv_a = 1/a.
-template <typename real>
-RTK_DEV bool sphere_root(V3<real> cc, real radius, V3<real> o, V3<real> d, real a, real inv_a, real tmin, real tmax, real& root) {
+// TIE kernels: a root that EQUALS tmax is offered to `wins_tie()` (tie_sphere_wins on the lane's state).
+template <bool TIE = false, typename real, typename F>
+RTK_DEV bool sphere_root(V3<real> cc, real radius, V3<real> o, V3<real> d, real a, real inv_a, real tmin, real tmax, real& root, F&& wins_tie) {
     V3<real> oc = cc - o;
     real h = dot(d, oc);
     real c = length_squared(oc) - radius * radius;
@@ -267,17 +306,29 @@ RTK_DEV bool sphere_root(V3<real> cc, real radius, V3<real> o, V3<real> d, real 
     if (disc < real(0)) return false;
     real sq = rt_sqrt(disc);
     real r = divide_by(h - sq, a, inv_a);
-    if (!(tmin < r && r < tmax)) {
+    bool ok = tmin < r && r < tmax;
+    if constexpr (TIE) {
+        if (r == tmax && tmin < r) ok = wins_tie();
+    }
+    if (!ok) {
         r = divide_by(h + sq, a, inv_a);
-        if (!(tmin < r && r < tmax)) return false;
+        ok = tmin < r && r < tmax;
+        if constexpr (TIE) {
+            if (r == tmax && tmin < r) ok = wins_tie();
+        }
+        if (!ok) return false;
     }
     root = r;
     return true;
 }
+template <typename real>
+RTK_DEV bool sphere_root(V3<real> cc, real radius, V3<real> o, V3<real> d, real a, real inv_a, real tmin, real tmax, real& root) {
+    return sphere_root<false>(cc, radius, o, d, a, inv_a, tmin, tmax, root, [] { return false; });
+}
 
 // quad::hit (quad.h:29-73) on the packed record n(3),D,Q(3),w(3),v(3),u(3).
-template <typename real>
-RTK_DEV bool quad_test(const Slot<real>* rec, V3<real> o, V3<real> d, real tmin, real tmax, real& t_out, real& alpha, real& beta) {
+template <typename real, typename Rec>
+RTK_DEV bool quad_test(const Rec* rec, V3<real> o, V3<real> d, real tmin, real tmax, real& t_out, real& alpha, real& beta) {
     V3<real> n = packed3<real, 0>(rec);
     real denom = dot(n, d);
     if (rt_fabs(denom) < real(1e-8)) return false;
@@ -296,8 +347,8 @@ RTK_DEV bool quad_test(const Slot<real>* rec, V3<real> o, V3<real> d, real tmin,
 // triangle::hit (triangle.h:65-122): Moeller-Trumbore with the reference's float
 // determinant (triangle.h:72,77) and float barycentrics (triangle.h:96-98), on
 // the packed record e2(3),e1(3),p0(3).
-template <typename real>
-RTK_DEV bool tri_test(const Slot<real>* rec, V3<real> o, V3<real> d, real tmin, real tmax, real& t_out, float& fa, float& fb, float& fg) {
+template <typename real, typename Rec>
+RTK_DEV bool tri_test(const Rec* rec, V3<real> o, V3<real> d, real tmin, real tmax, real& t_out, float& fa, float& fb, float& fg) {
     V3<real> e2 = packed3<real, 0>(rec), e1 = packed3<real, 3>(rec);
     V3<real> pvec = cross(d, e2);
     float det = float(dot(e1, pvec));
@@ -415,7 +466,68 @@ RTK_DEV void begin_segment(Lane<real>& L, Counters<COUNT>& cnt, float extent = 0
     L.pc = 0;
 }
 
-// ---- F_F32_BOX: the steps on the MIXED program (rtk_device_layout.h) -----------------------------------------
+// What a primitive test needs to resolve an exact tie (see "exact ties" above): the rank table of the program the kernel
+// executes and a way to learn the kind of the record at a pc (the current winner's).  TieCtx<false, ...> compiles to nothing.
+template <bool TIE, typename KindOf>
+struct TieCtx {
+    static constexpr bool enabled = TIE;
+    const uint32_t* ranks;
+    KindOf kind_of;
+    RTK_DEV bool sphere_wins(uint32_t pc, uint32_t best_pc) const { return tie_sphere_wins(ranks, pc, best_pc, best_pc == kNoHit ? 0u : kind_of(best_pc)); }
+    RTK_DEV bool inclusive_wins(uint32_t pc, uint32_t best_pc) const { return tie_inclusive_wins(ranks, pc, best_pc, best_pc == kNoHit ? 0u : kind_of(best_pc)); }
+};
+struct NoTie {
+    static constexpr bool enabled = false;
+    RTK_DEV bool sphere_wins(uint32_t, uint32_t) const { return false; }
+    RTK_DEV bool inclusive_wins(uint32_t, uint32_t) const { return true; }
+};
+
+// A primitive test accepted t: it is the closest hit so far (hittable_list.h:27-31 / bvh.h:69 shrink the interval).
+template <bool MIXED, typename real>
+RTK_DEV void take_hit(Lane<real>& L, real t) {
+    L.best_t = t;
+    L.best_pc = L.pc;
+    if constexpr (MIXED) L.tmax32 = above(t);
+}
+// The three primitive tests against the lane's current ray and interval, shared by every program layout: `units` is the
+// record's length in that layout; MIXED kernels keep the float copy of the interval in step.
+template <bool XF, bool MIXED, typename real, bool COUNT, typename Tie>
+RTK_DEV void hit_sphere(Lane<real>& L, V3<real> cc, real radius, uint32_t units, Counters<COUNT>& cnt, const Tie& tie) {
+    cnt.inc(C_SPHERE);
+    real r;
+    if (sphere_root<Tie::enabled>(cc, radius, ray_o<XF>(L), ray_d<XF>(L), L.a, L.inv_a, L.tmin, L.best_t, r, [&] { return tie.sphere_wins(L.pc, L.best_pc); }))
+        take_hit<MIXED>(L, r);
+    L.pc += units;
+}
+template <bool XF, bool MIXED, typename real, bool COUNT, typename Rec, typename Tie>
+RTK_DEV void hit_quad(Lane<real>& L, const Rec* __restrict__ rec, uint32_t units, Counters<COUNT>& cnt, const Tie& tie) {
+    cnt.inc(C_QUAD);
+    real t, al, be;
+    if (quad_test(rec, ray_o<XF>(L), ray_d<XF>(L), L.tmin, L.best_t, t, al, be)) {
+        bool ok = true;
+        if constexpr (Tie::enabled) {
+            if (t == L.best_t) ok = tie.inclusive_wins(L.pc, L.best_pc);
+        }
+        if (ok) take_hit<MIXED>(L, t);
+    }
+    L.pc += units;
+}
+template <bool XF, bool MIXED, typename real, bool COUNT, typename Rec, typename Tie>
+RTK_DEV void hit_tri(Lane<real>& L, const Rec* __restrict__ rec, uint32_t units, Counters<COUNT>& cnt, const Tie& tie) {
+    cnt.inc(C_TRI);
+    real t;
+    float fa, fb, fg;
+    if (tri_test(rec, ray_o<XF>(L), ray_d<XF>(L), L.tmin, L.best_t, t, fa, fb, fg)) {
+        bool ok = true;
+        if constexpr (Tie::enabled) {
+            if (t == L.best_t) ok = tie.inclusive_wins(L.pc, L.best_pc);
+        }
+        if (ok) take_hit<MIXED>(L, t);
+    }
+    L.pc += units;
+}
+
+// ---- F_F32_BOX: the steps on the MIXED / COMPACT programs (rtk_device_layout.h) -------------------------------
 // Conservative slab test in float: the same min/max structure as slab_test_fma on bounds that were rounded outward
 // and grown for exactly this arithmetic.  v_max3/v_min3 fold the reduction.
 RTK_DEV bool slab_test32(const MixedHead& b, V3<float> oi, V3<float> inv, float tmin, float tmax) {
@@ -429,53 +541,46 @@ RTK_DEV bool slab_test32(const MixedHead& b, V3<float> oi, V3<float> inv, float 
     const float far = raw_min(raw_min3(fx, fy, fz), tmax);
     return far >= near;  // >= : a tie is let through (conservative)
 }
-template <typename real, bool COUNT>
+// UNITS = length of a box record: 1 in the MIXED program (32-byte units), 2 in the COMPACT one (16-byte units)
+template <uint32_t UNITS = 1, typename real, bool COUNT>
 RTK_DEV void step_box32(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cnt) {
     cnt.inc(C_BOX);
     const bool hit = slab_test32(rec, L.oi32, L.inv32, L.tmin32, L.tmax32);
-    L.pc = hit ? L.pc + 1 : rec.aux;
+    L.pc = hit ? L.pc + UNITS : rec.aux;
 }
-// A box of the MIXED program for a ray the float test must not judge (zero / out-of-range direction component, origin
+// A box of those programs for a ray the float test must not judge (zero / out-of-range direction component, origin
 // outside the sized bound): aabb::hit's literal form in f64 on the (outward-rounded, hence still enclosing) bounds.
-template <typename real, bool COUNT>
+template <bool XF = false, uint32_t UNITS = 1, typename real, bool COUNT>
 RTK_DEV void step_box_mixed_exact(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cnt) {
     cnt.inc(C_BOX);
     Slot<real> b;
     for (int k = 0; k < 6; k++) b.v[k] = real(rec.f[k]);
-    const V3<real> inv = mk(real(1) / L.rd.x, real(1) / L.rd.y, real(1) / L.rd.z);
-    const bool hit = slab_test<true>(b, L.ro, inv, L.tmin, L.best_t);
-    L.pc = hit ? L.pc + 1 : rec.aux;
+    const V3<real> d = ray_d<XF>(L);
+    const V3<real> inv = mk(real(1) / d.x, real(1) / d.y, real(1) / d.z);
+    const bool hit = slab_test<true>(b, ray_o<XF>(L), inv, L.tmin, L.best_t);
+    L.pc = hit ? L.pc + UNITS : rec.aux;
 }
 // sphere::hit on a MIXED record: centre in the head unit, radius in the next one.
-template <typename real, bool COUNT>
-RTK_DEV void step_sphere_mixed(Lane<real>& L, const MixedHead& head, const MixedHead* __restrict__ rec, Counters<COUNT>& cnt) {
-    cnt.inc(C_SPHERE);
+template <typename real, bool COUNT, typename Tie>
+RTK_DEV void step_sphere_mixed(Lane<real>& L, const MixedHead& head, const MixedHead* __restrict__ rec, Counters<COUNT>& cnt, const Tie& tie) {
     const double radius = reinterpret_cast<const double*>(rec + 1)[0];
-    real r;
-    if (sphere_root(mk(real(head.d[0]), real(head.d[1]), real(head.d[2])), real(radius), L.ro, L.rd, L.a, L.inv_a, L.tmin, L.best_t, r)) {
-        L.best_t = r;
-        L.best_pc = L.pc;
-        L.tmax32 = above(r);
-    }
-    L.pc += 2;
+    hit_sphere<false, true>(L, mk(real(head.d[0]), real(head.d[1]), real(head.d[2])), real(radius), 2u, cnt, tie);
+}
+// ... and on a COMPACT record (3 units): the head (centre) is usually in registers already, the radius follows it.
+template <bool XF, typename real, bool COUNT, typename Tie>
+RTK_DEV void step_sphere_compact(Lane<real>& L, const MixedHead& head, const Unit16* __restrict__ rec, Counters<COUNT>& cnt, const Tie& tie) {
+    hit_sphere<XF, true>(L, mk(real(head.d[0]), real(head.d[1]), real(head.d[2])), packed<real, 3>(rec), 3u, cnt, tie);
 }
 // The remaining record kinds of a sphere-only program: a moving sphere, or a box for an irregular ray.
-template <typename real, bool COUNT>
-RTK_DEV void step_other_mixed(Lane<real>& L, const MixedHead* __restrict__ rec, Counters<COUNT>& cnt) {
+template <typename real, bool COUNT, typename Tie>
+RTK_DEV void step_other_mixed(Lane<real>& L, const MixedHead* __restrict__ rec, Counters<COUNT>& cnt, const Tie& tie) {
     const uint32_t kind = rec->kind_payload & 15u;
     if (kind == OP_BOX) {
         step_box_mixed_exact(L, *rec, cnt);
     } else if (kind == OP_SPHERE_MOVING) {
-        cnt.inc(C_SPHERE);
         const double* cont = reinterpret_cast<const double*>(rec + 1);
         const V3<real> cc = mk(real(rec->d[0]), real(rec->d[1]), real(rec->d[2])) + scale(L.tm, mk(real(cont[2]), real(cont[3]), real(cont[4])));
-        real r;
-        if (sphere_root(cc, real(cont[0]), L.ro, L.rd, L.a, L.inv_a, L.tmin, L.best_t, r)) {
-            L.best_t = r;
-            L.best_pc = L.pc;
-            L.tmax32 = above(r);
-        }
-        L.pc += 3;
+        hit_sphere<false, true>(L, cc, real(cont[0]), 3u, cnt, tie);
     } else {
         L.pc += uint32_t(mixed_units(kind));  // unreachable for a validated sphere-only program
     }
@@ -491,61 +596,44 @@ RTK_DEV void step_box(Lane<real>& L, const Slot<real>& rec, Counters<COUNT>& cnt
 }
 
 // sphere::hit of a stationary sphere.
-template <bool XF, typename real, bool COUNT>
-RTK_DEV void step_sphere(Lane<real>& L, const Slot<real>& rec, Counters<COUNT>& cnt) {
-    cnt.inc(C_SPHERE);
-    real r;
-    if (sphere_root(mk(rec.v[0], rec.v[1], rec.v[2]), rec.v[3], ray_o<XF>(L), ray_d<XF>(L), L.a, L.inv_a, L.tmin, L.best_t, r)) {
-        L.best_t = r;
-        L.best_pc = L.pc;
-    }
-    L.pc += 1;
+template <bool XF, typename real, bool COUNT, typename Tie>
+RTK_DEV void step_sphere(Lane<real>& L, const Slot<real>& rec, Counters<COUNT>& cnt, const Tie& tie) {
+    hit_sphere<XF, false>(L, mk(rec.v[0], rec.v[1], rec.v[2]), rec.v[3], 1u, cnt, tie);
 }
 
-// Every other record kind (moving sphere, quad, triangle, chain switch, the three
-// medium ops).  `rec` points at the record in the program (LDS or global).
-template <typename real, uint32_t FEAT, bool COUNT>
-RTK_DEV void step_other(Lane<real>& L, const Slot<real>* __restrict__ rec, const SceneView<real>& sc, Counters<COUNT>& cnt) {
+// Every other record kind (moving sphere, quad, triangle, chain switch, the three medium ops, a box met by a ray the
+// box loop does not take).  `rec` points at the record in the program (LDS or global), in the slot layout (Slot<real>)
+// or -- F_F32_BOX kernels of the non-lean families -- the COMPACT one (Unit16).
+template <typename real, uint32_t FEAT, bool COUNT, typename Rec, typename Tie>
+RTK_DEV void step_other(Lane<real>& L, const Rec* __restrict__ rec, const SceneView<real>& sc, Counters<COUNT>& cnt, const Tie& tie, float extent = 0.0f) {
     constexpr bool XF = (FEAT & F_XFORM) != 0;
-    const uint32_t kp = rec->kind_payload;
+    constexpr bool MIXED = (FEAT & F_F32_BOX) != 0;  // here: the COMPACT program (f32 culling boxes; the float interval follows every change)
+    const uint32_t kp = rec_kind_payload<real>(rec);
+    const uint32_t aux = rec_aux<real>(rec);
     const uint32_t kind = kp & 15u;
     if (kind == OP_BOX) {  // only for rays with a zero or infinite direction component: the literal, NaN-exact slab test
-        step_box<true, XF>(L, *rec, cnt);
+        if constexpr (MIXED) step_box_mixed_exact<XF, 2>(L, *reinterpret_cast<const MixedHead*>(rec), cnt);
+        else step_box<true, XF>(L, *reinterpret_cast<const Slot<real>*>(rec), cnt);
     } else if (kind == OP_SPHERE_MOVING) {
-        cnt.inc(C_SPHERE);
-        real r;
-        V3<real> cc = mk(rec->v[0], rec->v[1], rec->v[2]) + scale(L.tm, mk(rec[1].v[0], rec[1].v[1], rec[1].v[2]));
-        if (sphere_root(cc, rec->v[3], ray_o<XF>(L), ray_d<XF>(L), L.a, L.inv_a, L.tmin, L.best_t, r)) {
-            L.best_t = r;
-            L.best_pc = L.pc;
-        }
-        L.pc += 2;
+        const V3<real> cc = packed3<real, 0>(rec) + scale(L.tm, moving_dir<real>(rec));
+        hit_sphere<XF, MIXED>(L, cc, packed<real, 3>(rec), rec_units<real>(rec, kind), cnt, tie);
     } else if ((FEAT & F_QUAD) && kind == OP_QUAD) {
-        cnt.inc(C_QUAD);
-        real t, al, be;
-        if (quad_test(rec, ray_o<XF>(L), ray_d<XF>(L), L.tmin, L.best_t, t, al, be)) {
-            L.best_t = t;
-            L.best_pc = L.pc;
-        }
-        L.pc += 3;
+        hit_quad<XF, MIXED>(L, rec, rec_units<real>(rec, kind), cnt, tie);
     } else if ((FEAT & F_TRI) && kind == OP_TRI) {
-        cnt.inc(C_TRI);
-        real t;
-        float fa, fb, fg;
-        if (tri_test(rec, ray_o<XF>(L), ray_d<XF>(L), L.tmin, L.best_t, t, fa, fb, fg)) {
-            L.best_t = t;
-            L.best_pc = L.pc;
-        }
-        L.pc += 2;
+        hit_tri<XF, MIXED>(L, rec, rec_units<real>(rec, kind), cnt, tie);
     } else if ((FEAT & F_XFORM) && kind == OP_CHAIN) {
-        cnt.inc(C_XFORM, rec->aux);
+        cnt.inc(C_XFORM, aux);
         apply_chain(sc.chains, kp >> 4, L.ro, L.rd, L.o, L.d);
-        L.inv = mk(real(1) / L.d.x, real(1) / L.d.y, real(1) / L.d.z);
         L.a = length_squared(L.d);
         L.inv_a = real(1) / L.a;
-        L.box_kind = regular_direction(L.inv) ? uint32_t(OP_BOX) : kIrregularBox;
-        L.oi = L.o * L.inv;
-        L.pc += 1;
+        if constexpr (MIXED) {
+            begin_culling32(L, L.o, L.d, extent);  // 1/d, o/d in float for the boxes of this space; the interval (a ray parameter) is unchanged
+        } else {
+            L.inv = mk(real(1) / L.d.x, real(1) / L.d.y, real(1) / L.d.z);
+            L.box_kind = regular_direction(L.inv) ? uint32_t(OP_BOX) : kIrregularBox;
+            L.oi = L.o * L.inv;
+        }
+        L.pc += rec_units<real>(rec, kind);
     } else if ((FEAT & F_MEDIA) && kind == OP_MED_BEGIN) {
         cnt.inc(C_MEDIUM);
         L.sv_tmin = L.tmin;
@@ -554,20 +642,22 @@ RTK_DEV void step_other(Lane<real>& L, const Slot<real>* __restrict__ rec, const
         L.tmin = -real_inf<real>();
         L.best_t = real_inf<real>();
         L.best_pc = kNoHit;
-        L.pc += 1;
+        L.pc += rec_units<real>(rec, kind);
+        if constexpr (MIXED) sync_interval32(L);
     } else if ((FEAT & F_MEDIA) && kind == OP_MED_MID) {
         if (L.best_pc == kNoHit) {  // constant_medium.h:23-24
             L.tmin = L.sv_tmin;
             L.best_t = L.sv_best_t;
             L.best_pc = L.sv_best_pc;
-            L.pc = rec->aux;
+            L.pc = aux;
         } else {
             L.rec1_t = L.best_t;
             L.tmin = L.rec1_t + real(0.0001);  // constant_medium.h:26
             L.best_t = real_inf<real>();
             L.best_pc = kNoHit;
-            L.pc += 1;
+            L.pc += rec_units<real>(rec, kind);
         }
+        if constexpr (MIXED) sync_interval32(L);
     } else if ((FEAT & F_MEDIA) && kind == OP_MED_END) {
         const bool hit2 = L.best_pc != kNoHit;
         real r2 = L.best_t;
@@ -582,16 +672,17 @@ RTK_DEV void step_other(Lane<real>& L, const Slot<real>* __restrict__ rec, const
                 if (r1 < real(0)) r1 = real(0);
                 const real ray_length = rt_sqrt(L.a);
                 const real inside = (r2 - r1) * ray_length;
-                const real hit_distance = rec->v[0] * rt_log(rnd<real>(L.rng, cnt));
+                const real hit_distance = packed<real, 0>(rec) * rt_log(rnd<real>(L.rng, cnt));
                 if (!(hit_distance > inside)) {
                     L.best_t = r1 + hit_distance / ray_length;
                     L.best_pc = L.pc;
                 }
             }
         }
-        L.pc += 1;
+        L.pc += rec_units<real>(rec, kind);
+        if constexpr (MIXED) sync_interval32(L);
     } else {
-        L.pc += 1;  // unreachable for a validated program
+        L.pc += rec_units<real>(rec, kind);  // unreachable for a validated program
     }
 }
 
@@ -705,16 +796,18 @@ RTK_DEV void make_surface_mixed(const MixedHead* __restrict__ prog, uint32_t bes
 
 
 // Build the hit record of the winning record (the deferred half of *.hit).  Sphere
-// and quad geometry is read from the program slot itself (LDS when staged); only
-// triangles go to their side record for the normal and the UVs.
-template <typename real, uint32_t FEAT>
-RTK_DEV void make_surface(const Slot<real>* __restrict__ prog, const SceneView<real>& sc, const MaterialRec<real>* __restrict__ mats, uint32_t best_pc, real t,
+// and quad geometry is read from the program record itself (LDS when staged); only
+// triangles go to their side record for the normal and the UVs.  `prog` is the slot
+// program or the COMPACT one (same payload element numbering in both).
+template <typename real, uint32_t FEAT, typename Rec>
+RTK_DEV void make_surface(const Rec* __restrict__ prog, const SceneView<real>& sc, const MaterialRec<real>* __restrict__ mats, uint32_t best_pc, real t,
                           V3<real> wo, V3<real> wd, real tm, Surface<real>& sf, bool force_uv = false) {
-    const Slot<real>* rec = prog + best_pc;
-    const uint32_t kind = rec->kind_payload & 15u;
-    const uint32_t idx = rec->kind_payload >> 4;
-    const uint32_t chain = (FEAT & F_XFORM) ? (rec->aux & 255u) : 0u;
-    sf.material = int(rec->aux >> 8);
+    const Rec* rec = prog + best_pc;
+    const uint32_t kp = rec_kind_payload<real>(rec), aux = rec_aux<real>(rec);
+    const uint32_t kind = kp & 15u;
+    const uint32_t idx = kp >> 4;
+    const uint32_t chain = (FEAT & F_XFORM) ? (aux & 255u) : 0u;
+    sf.material = int(aux >> 8);
     V3<real> o = wo, d = wd;
     if (FEAT & F_XFORM) apply_chain(sc.chains, chain, wo, wd, o, d);
     sf.p = o + scale(t, d);
@@ -723,9 +816,9 @@ RTK_DEV void make_surface(const Slot<real>* __restrict__ prog, const SceneView<r
     V3<real> outward;
     bool face_from_ray = true;
     if (kind == OP_SPHERE || kind == OP_SPHERE_MOVING) {  // sphere.h:50-56,67-73
-        V3<real> cc = mk(rec->v[0], rec->v[1], rec->v[2]);
-        if (kind == OP_SPHERE_MOVING) cc = cc + scale(tm, mk(rec[1].v[0], rec[1].v[1], rec[1].v[2]));
-        outward = scale(rec->v[4], sf.p - cc);  // (p - center) / radius = (1/radius) * (p - center) (vec3.h:91-93); v[4] = 1/radius from the upload
+        V3<real> cc = packed3<real, 0>(rec);
+        if (kind == OP_SPHERE_MOVING) cc = cc + scale(tm, moving_dir<real>(rec));
+        outward = scale(packed<real, 4>(rec), sf.p - cc);  // (p - center) / radius = (1/radius) * (p - center) (vec3.h:91-93); element 4 = 1/radius from the upload
         if ((FEAT & F_TEXTURE) && (force_uv || mats[sf.material].needs_uv)) {
             const real pi = real(3.1415926535897932385);
             real theta = rt_acos(-outward.y);
@@ -822,8 +915,8 @@ RTK_DEV bool shade(Lane<real>& L, const ProgT* __restrict__ prog, const SceneVie
     }
     cnt.inc(C_SURFACE);
     Surface<real> sf;
-    if constexpr (FEAT & F_F32_BOX) make_surface_mixed(prog, L.best_pc, L.best_t, L.ro, L.rd, L.tm, sf);
-    else make_surface<real, FEAT>(prog, sc, mats, L.best_pc, L.best_t, L.ro, L.rd, L.tm, sf);
+    if constexpr (std::is_same_v<ProgT, MixedHead>) make_surface_mixed(prog, L.best_pc, L.best_t, L.ro, L.rd, L.tm, sf);  // lean MIXED program
+    else make_surface<real, FEAT>(prog, sc, mats, L.best_pc, L.best_t, L.ro, L.rd, L.tm, sf);                             // slot or COMPACT program
     const MaterialRec<real>& m = mats[sf.material];
     const V3<real> rd = L.rd;
 
@@ -1054,14 +1147,21 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
 #endif
     constexpr uint32_t FEAT = FEAT_ALL & ~uint32_t(F_LDS_BOXES) & ~uint32_t(RTK_DEV_MASK_OFF);
     constexpr bool SPLIT = (FEAT_ALL & F_LDS_BOXES) != 0;  // boxes, kinds and the rank table in LDS; everything else of the program in HBM/L2
-    static_assert(!SPLIT || (!IN_LDS && (FEAT & F_F32_BOX) == 0), "F_LDS_BOXES: for programs that do not fit LDS");
-    constexpr bool MIXED = (FEAT & F_F32_BOX) != 0;  // the MIXED program: f32 culling boxes, 32-byte units (f64, sphere-only scenes)
-    static_assert(!MIXED || (sizeof(real) == 8 && (FEAT & ~uint32_t(F_F32_BOX)) == kFeatLean), "F_F32_BOX: lean f64 kernels only");
-    using ProgRec = std::conditional_t<MIXED, MixedHead, Slot<real>>;
+    static_assert(!SPLIT || !IN_LDS, "F_LDS_BOXES: for programs that do not fit LDS");
+    constexpr bool MIXED = (FEAT & F_F32_BOX) != 0;  // f32 culling boxes + exact primitives (f64 kernels, fast order): ...
+    // ... the MIXED program of sphere-only scenes (32-byte units) or, for every other family, the COMPACT program (16-byte units)
+    constexpr bool COMPACT = MIXED && (FEAT & ~uint32_t(F_F32_BOX | F_MATTE)) != kFeatLean;
+    static_assert(!MIXED || sizeof(real) == 8, "F_F32_BOX: f64 kernels only");
+    static_assert(!SPLIT || !MIXED || COMPACT, "F_LDS_BOXES with f32 boxes: the COMPACT program");
+    constexpr bool XF = (FEAT & F_XFORM) != 0;
+    using ProgRec = std::conditional_t<COMPACT, Unit16, std::conditional_t<MIXED, MixedHead, Slot<real>>>;  // what pc counts
+    using CurRec = std::conditional_t<MIXED, MixedHead, Slot<real>>;                                      // the record head a step holds in registers
+    constexpr uint32_t kBoxUnits = COMPACT ? 2u : 1u, kSphereUnits = COMPACT ? 3u : (MIXED ? 2u : 1u), kQuadUnits = COMPACT ? 9u : 3u, kTriUnits = COMPACT ? 5u : 2u;
     const ProgRec* prog;
-    if constexpr (MIXED) prog = sc.program_mixed;
+    if constexpr (COMPACT) prog = sc.program_compact;
+    else if constexpr (MIXED) prog = sc.program_mixed;
     else prog = sc.program;
-    const int n_records = MIXED ? sc.n_units : sc.n_slots;  // units of sizeof(ProgRec)
+    const int n_records = COMPACT ? sc.n_units16 : (MIXED ? sc.n_units : sc.n_slots);  // units of sizeof(ProgRec)
     const MaterialRec<real>* mats = sc.materials;
     if constexpr (IN_LDS) {  // program, then the material table, both as 16-byte words
         const int n_prog16 = n_records * int(sizeof(ProgRec) / 16);
@@ -1075,38 +1175,67 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
         prog = reinterpret_cast<const ProgRec*>(lds_program);
         mats = reinterpret_cast<const MaterialRec<real>*>(lds_program + size_t(n_prog16) * 16);
     }
-    [[maybe_unused]] const BoxRec<real>* lds_boxes = nullptr;
+    using BoxCacheRec = std::conditional_t<COMPACT, MixedHead, BoxRec<real>>;  // what F_LDS_BOXES keeps per box
+    [[maybe_unused]] const BoxCacheRec* lds_boxes = nullptr;
     [[maybe_unused]] const uint32_t* lds_kinds = nullptr;
     [[maybe_unused]] const uint2* lds_rank = nullptr;
     if constexpr (SPLIT) {
-        const size_t box_bytes = size_t(sc.n_cached_boxes) * sizeof(BoxRec<real>);  // a multiple of 8
-        const uint2* __restrict__ src = reinterpret_cast<const uint2*>(sc.box_cache);
+        const BoxCacheRec* cache;
+        const uint32_t* kind_words;
+        const uint2* box_rank;
+        int n_boxes, n_kind_words, n_rank_words;
+        if constexpr (COMPACT) {
+            cache = sc.box_cache16; kind_words = sc.kind_words16; box_rank = sc.box_rank16;
+            n_boxes = sc.n_cached_boxes16; n_kind_words = sc.n_kind_words16; n_rank_words = sc.n_rank_words16;
+        } else {
+            cache = sc.box_cache; kind_words = sc.kind_words; box_rank = sc.box_rank;
+            n_boxes = sc.n_cached_boxes; n_kind_words = sc.n_kind_words; n_rank_words = sc.n_rank_words;
+        }
+        const size_t box_bytes = size_t(n_boxes) * sizeof(BoxCacheRec);  // a multiple of 8
+        const uint2* __restrict__ src = reinterpret_cast<const uint2*>(cache);
         uint2* dst = reinterpret_cast<uint2*>(lds_program);
         for (int k = threadIdx.x; k < int(box_bytes / 8); k += blockDim.x) dst[k] = src[k];
         uint32_t* kdst = reinterpret_cast<uint32_t*>(lds_program + box_bytes);
-        for (int k = threadIdx.x; k < sc.n_kind_words; k += blockDim.x) kdst[k] = sc.kind_words[k];
-        uint2* rdst = reinterpret_cast<uint2*>(lds_program + box_bytes + ((size_t(sc.n_kind_words) * 4 + 7) & ~size_t(7)));
-        for (int k = threadIdx.x; k < sc.n_rank_words; k += blockDim.x) rdst[k] = sc.box_rank[k];
+        for (int k = threadIdx.x; k < n_kind_words; k += blockDim.x) kdst[k] = kind_words[k];
+        uint2* rdst = reinterpret_cast<uint2*>(lds_program + box_bytes + ((size_t(n_kind_words) * 4 + 7) & ~size_t(7)));
+        for (int k = threadIdx.x; k < n_rank_words; k += blockDim.x) rdst[k] = box_rank[k];
         __syncthreads();
-        lds_boxes = reinterpret_cast<const BoxRec<real>*>(lds_program);
+        lds_boxes = reinterpret_cast<const BoxCacheRec*>(lds_program);
         lds_kinds = kdst;
         lds_rank = rdst;
     }
-    // kind of the record that starts at slot pc; the box record at pc (SPLIT: from the LDS copies)
+    // the head of the record that starts at pc, as a step holds it in registers
+    auto head_at = [&](uint32_t pc) -> CurRec {
+        if constexpr (COMPACT) return *reinterpret_cast<const MixedHead*>(prog + pc);
+        else return prog[pc];
+    };
+    // kind of the record that starts at pc; the box record at pc (SPLIT: from the LDS copies)
     auto kind_of = [&](uint32_t pc) -> uint32_t {
         if constexpr (SPLIT) return (lds_kinds[pc >> 3] >> ((pc & 7u) * 4u)) & 15u;
+        else if constexpr (COMPACT) return prog[pc + 1].w[2] & 15u;
         else return prog[pc].kind_payload & 15u;
     };
-    [[maybe_unused]] auto box_at = [&](uint32_t pc) -> Slot<real> {
+    [[maybe_unused]] auto box_at = [&](uint32_t pc) -> CurRec {
         const uint2 e = lds_rank[pc >> 5];
-        const BoxRec<real> b = lds_boxes[e.y + uint32_t(__builtin_popcount(e.x & ((1u << (pc & 31u)) - 1u)))];
-        Slot<real> s;
+        const uint32_t at = e.y + uint32_t(__builtin_popcount(e.x & ((1u << (pc & 31u)) - 1u)));
+        if constexpr (COMPACT) {
+            return lds_boxes[at];
+        } else if constexpr (MIXED) {
+            return CurRec{};  // (the MIXED program of sphere-only scenes always fits LDS: no boxes-in-LDS kernel)
+        } else {
+            const BoxRec<real> b = lds_boxes[at];
+            Slot<real> s;
 #pragma unroll
-        for (int k = 0; k < 6; k++) s.v[k] = b.v[k];
-        s.kind_payload = OP_BOX;
-        s.aux = b.aux;
-        return s;
+            for (int k = 0; k < 6; k++) s.v[k] = b.v[k];
+            s.kind_payload = OP_BOX;
+            s.aux = b.aux;
+            return s;
+        }
     };
+    // exact ties between primitives are resolved by the reference's ranks in the kernels that run re-grouped hierarchies
+    // (the quad/box subset kernel serves the fast order without a flag of its own)
+    constexpr bool TIE = (FEAT & (F_FMA_BOX | F_F32_BOX)) != 0 || (FEAT & ~uint32_t(F_MATTE)) == kFeatQuadBox;
+    const TieCtx<TIE, decltype(kind_of)> tie{TIE ? (MIXED ? sc.tie_rank : sc.tie_rank_slot) : nullptr, kind_of};
     // The hand-out order of the tiles (learned from the previous frame) is staged behind the program when the host
     // found room for it (tmap.order_in_lds): a lookup per work item from LDS instead of a cold global load.
     const int32_t* lds_order = nullptr;
@@ -1124,7 +1253,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
     const uint32_t seed_hash = pcg_hash(seed);
     const int n_tiles_total = tmap.tiles_x * tmap.tiles_y;
     const int width = cam.width, height = cam.height, spp = cam.spp;
-    const uint32_t end_pc = uint32_t(n_records - 1);  // OP_END is one unit in either layout
+    const uint32_t end_pc = uint32_t(n_records - (COMPACT ? 2 : 1));  // OP_END: the last record (two units in the COMPACT layout)
     const float extent = sc.extent;
     Counters<COUNT> cnt;
     cnt.clear();
@@ -1146,7 +1275,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
     // defaults per kernel family (tools/variant_sweep.py): MIXED 12 (24.5 vs 24.7 ms at 16); full-feature 4 (C5 297.3 -> 283.4 ms; 8: 285.7);
     // mesh subset 8 (C4 +1 %); 16 elsewhere
     constexpr uint32_t kFamily = FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE);
-    constexpr int kSphereMinDefault = (FEAT & F_F32_BOX) ? 12 : (kFamily == kFeatAll ? 4 : (kFamily == kFeatMesh ? 8 : 16));
+    constexpr int kSphereMinDefault = (MIXED && !COMPACT) ? 12 : (kFamily == kFeatAll ? 4 : (kFamily == kFeatMesh ? 8 : 16));
     const int sphere_min = sphere_sel == 0 ? kSphereMinDefault : kSphereMinTable[sphere_sel];
 
     Lane<real> L;
@@ -1291,8 +1420,17 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
 #ifndef RTK_UNROLL_SPLIT
 #define RTK_UNROLL_SPLIT 4
 #endif
-            constexpr int kBoxUnroll = (SPLIT && RTK_UNROLL_SPLIT > 0) ? RTK_UNROLL_SPLIT : ((MIXED || FEAT == (kFeatLean | uint32_t(F_FMA_BOX))) ? RTK_UNROLL_MIXED : ((FEAT & ~uint32_t(F_FMA_BOX)) == kFeatAll ? 2 : ((FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatQuadBox ? RTK_UNROLL_QUADBOX : ((FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatMesh ? RTK_UNROLL_MESH : RTK_UNROLL_LEAN))));
-            ProgRec cur;  // the record at L.pc (its first 32 bytes in the MIXED layout), held in registers: one LDS round trip per step
+#ifndef RTK_UNROLL_COMPACT_QUADBOX
+#define RTK_UNROLL_COMPACT_QUADBOX 2
+#endif
+#ifndef RTK_UNROLL_COMPACT_MESH
+#define RTK_UNROLL_COMPACT_MESH 4
+#endif
+            constexpr int kBoxUnroll = (SPLIT && RTK_UNROLL_SPLIT > 0) ? RTK_UNROLL_SPLIT
+                                       : (((MIXED && !COMPACT) || FEAT == (kFeatLean | uint32_t(F_FMA_BOX))) ? RTK_UNROLL_MIXED
+                                          : (kFamily == kFeatAll ? 2 : (kFamily == kFeatQuadBox ? (COMPACT ? RTK_UNROLL_COMPACT_QUADBOX : RTK_UNROLL_QUADBOX)
+                                                                       : (kFamily == kFeatMesh ? (COMPACT ? RTK_UNROLL_COMPACT_MESH : RTK_UNROLL_MESH) : RTK_UNROLL_LEAN))));
+            CurRec cur;  // the record at L.pc (its first 32 bytes in the MIXED / COMPACT layouts), held in registers: one LDS round trip per step
             uint32_t k = kind;
             // the record at L.pc -> cur, its kind -> k.  SPLIT: the kind comes from the LDS nibble table and only boxes are
             // fetched (from the LDS copy); a primitive's record is read from memory by the step that tests it
@@ -1301,14 +1439,14 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                     k = kind_of(L.pc);
                     if (k == OP_BOX) cur = box_at(L.pc);
                 } else {
-                    cur = prog[L.pc];
+                    cur = head_at(L.pc);
                     k = cur.kind_payload & 15u;
                 }
             };
             if constexpr (SPLIT) {
                 if (k == OP_BOX) cur = box_at(L.pc);
             } else {
-                cur = prog[L.pc];
+                cur = head_at(L.pc);
             }
             const uint32_t box_kind = L.box_kind;  // a lane with an irregular ray matches nothing here: it never steps in this loop
             int remaining;
@@ -1318,8 +1456,8 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             // also keeps the loop populated for longer.
             do {
                 if (k == box_kind) {
-                    if constexpr (MIXED) step_box32(L, cur, cnt);
-                    else step_box<false, (FEAT & F_XFORM) != 0, (FEAT & F_FMA_BOX) != 0>(L, cur, cnt);
+                    if constexpr (MIXED) step_box32<kBoxUnits>(L, cur, cnt);
+                    else step_box<false, XF, (FEAT & F_FMA_BOX) != 0>(L, cur, cnt);
                     fetch();
                     L.kind = k;
                 }
@@ -1328,17 +1466,18 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                     // further box steps before the loop's scalar checks (vote / sphere / exit): the checks are a
                     // dependent v_cmp -> s_bcnt1 -> s_cmp -> branch chain per step, and the kernel is latency-bound
                     if (k == box_kind) {
-                        if constexpr (MIXED) step_box32(L, cur, cnt);
-                        else step_box<false, (FEAT & F_XFORM) != 0, (FEAT & F_FMA_BOX) != 0>(L, cur, cnt);
+                        if constexpr (MIXED) step_box32<kBoxUnits>(L, cur, cnt);
+                        else step_box<false, XF, (FEAT & F_FMA_BOX) != 0>(L, cur, cnt);
                         fetch();
                         L.kind = k;
                     }
                 }
                 if (popcount64(__ballot(k == OP_SPHERE)) >= sphere_min) {
                     if (k == OP_SPHERE) {
-                        if constexpr (SPLIT) cur = prog[L.pc];
-                        if constexpr (MIXED) step_sphere_mixed(L, cur, prog + L.pc, cnt);
-                        else step_sphere<(FEAT & F_XFORM) != 0>(L, cur, cnt);
+                        if constexpr (SPLIT) cur = head_at(L.pc);
+                        if constexpr (COMPACT) step_sphere_compact<XF>(L, cur, prog + L.pc, cnt, tie);
+                        else if constexpr (MIXED) step_sphere_mixed(L, cur, prog + L.pc, cnt, tie);
+                        else step_sphere<XF>(L, cur, cnt, tie);
                         fetch();
                         L.kind = k;
                     }
@@ -1358,14 +1497,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                     // C4 47.8 -> 42.5 ms at 16 lanes (8: 42.8, 24: 43.6)
                     if (popcount64(__ballot(k == OP_TRI)) >= RTK_TRI_RIDE) {
                         if (k == OP_TRI) {
-                            cnt.inc(C_TRI);
-                            real t;
-                            float fa, fb, fg;
-                            if (tri_test(prog + L.pc, ray_o<(FEAT & F_XFORM) != 0>(L), ray_d<(FEAT & F_XFORM) != 0>(L), L.tmin, L.best_t, t, fa, fb, fg)) {
-                                L.best_t = t;
-                                L.best_pc = L.pc;
-                            }
-                            L.pc += 2;
+                            hit_tri<XF, MIXED>(L, prog + L.pc, kTriUnits, cnt, tie);
                             fetch();
                             L.kind = k;
                         }
@@ -1373,16 +1505,10 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                 }
                 // ... and quad tests in the quad/box subset kernels (C3 31.9 -> 30.4 ms at 16 lanes, 30.8 at 24); the
                 // full-feature kernel has no registers for it (C5 298 -> 316 ms)
-                if constexpr ((FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatQuadBox && RTK_QUAD_RIDE > 0) {
+                if constexpr ((FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE)) == kFeatQuadBox && RTK_QUAD_RIDE > 0) {
                     if (popcount64(__ballot(k == OP_QUAD)) >= RTK_QUAD_RIDE) {
                         if (k == OP_QUAD) {
-                            cnt.inc(C_QUAD);
-                            real t, al, be;
-                            if (quad_test(prog + L.pc, ray_o<(FEAT & F_XFORM) != 0>(L), ray_d<(FEAT & F_XFORM) != 0>(L), L.tmin, L.best_t, t, al, be)) {
-                                L.best_t = t;
-                                L.best_pc = L.pc;
-                            }
-                            L.pc += 3;
+                            hit_quad<XF, MIXED>(L, prog + L.pc, kQuadUnits, cnt, tie);
                             fetch();
                             L.kind = k;
                         }
@@ -1396,18 +1522,19 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             const int ssel = int(diag >> 11) & 7;  // tools/: same for the sphere loop (0 = default)
             const int sfrac = (n_sph * (ssel == 0 ? 4 : ssel)) >> 3;
             const int keep = sfrac > 8 ? sfrac : 8;
-            ProgRec cur = prog[L.pc];
+            CurRec cur = head_at(L.pc);
             uint32_t k = kind;
             int remaining;
             do {
                 if (k == OP_SPHERE) {
-                    if constexpr (MIXED) step_sphere_mixed(L, cur, prog + L.pc, cnt);
-                    else step_sphere<(FEAT & F_XFORM) != 0>(L, cur, cnt);
+                    if constexpr (COMPACT) step_sphere_compact<XF>(L, cur, prog + L.pc, cnt, tie);
+                    else if constexpr (MIXED) step_sphere_mixed(L, cur, prog + L.pc, cnt, tie);
+                    else step_sphere<XF>(L, cur, cnt, tie);
                     if constexpr (SPLIT) {
                         k = kind_of(L.pc);
-                        if (k == OP_SPHERE) cur = prog[L.pc];
+                        if (k == OP_SPHERE) cur = head_at(L.pc);
                     } else {
-                        cur = prog[L.pc];
+                        cur = head_at(L.pc);
                         k = cur.kind_payload & 15u;
                     }
                     L.kind = k;
@@ -1423,13 +1550,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             int remaining;
             do {
                 if (k == OP_QUAD) {
-                    cnt.inc(C_QUAD);
-                    real t, al, be;
-                    if (quad_test(prog + L.pc, ray_o<(FEAT & F_XFORM) != 0>(L), ray_d<(FEAT & F_XFORM) != 0>(L), L.tmin, L.best_t, t, al, be)) {
-                        L.best_t = t;
-                        L.best_pc = L.pc;
-                    }
-                    L.pc += 3;
+                    hit_quad<XF, MIXED>(L, prog + L.pc, kQuadUnits, cnt, tie);
                     k = kind_of(L.pc);
                     L.kind = k;
                 }
@@ -1445,14 +1566,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             int remaining;
             do {
                 if (k == OP_TRI) {
-                    cnt.inc(C_TRI);
-                    real t;
-                    float fa, fb, fg;
-                    if (tri_test(prog + L.pc, ray_o<(FEAT & F_XFORM) != 0>(L), ray_d<(FEAT & F_XFORM) != 0>(L), L.tmin, L.best_t, t, fa, fb, fg)) {
-                        L.best_t = t;
-                        L.best_pc = L.pc;
-                    }
-                    L.pc += 2;
+                    hit_tri<XF, MIXED>(L, prog + L.pc, kTriUnits, cnt, tie);
                     k = kind_of(L.pc);
                     L.kind = k;
                 }
@@ -1521,8 +1635,8 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             RTK_PROF_MARK(3, 1, n_shd)
         } else {
             if (m_oth >> lane & 1ull) {
-                if constexpr (MIXED) step_other_mixed(L, prog + L.pc, cnt);
-                else step_other<real, FEAT, COUNT>(L, prog + L.pc, sc, cnt);
+                if constexpr (MIXED && !COMPACT) step_other_mixed(L, prog + L.pc, cnt, tie);
+                else step_other<real, FEAT, COUNT>(L, prog + L.pc, sc, cnt, tie, extent);
                 L.kind = kind_of(L.pc);
             }
             RTK_PROF_MARK(4, 1, n_oth)
@@ -1561,6 +1675,8 @@ __global__ __launch_bounds__(256) void rtk_debug_hit_kernel(SceneView<real> sc, 
     L.tmin = real(r[7]);
     L.best_t = real(r[8]);
     const Slot<real>* prog = sc.program;
+    auto kind_of = [&](uint32_t pc) -> uint32_t { return prog[pc].kind_payload & 15u; };
+    const TieCtx<true, decltype(kind_of)> tie{sc.tie_rank_slot, kind_of};  // inert (null table) for reference-order uploads
     for (;;) {
         const Slot<real>* rec = prog + L.pc;
         const uint32_t kind = rec->kind_payload & 15u;
@@ -1569,9 +1685,9 @@ __global__ __launch_bounds__(256) void rtk_debug_hit_kernel(SceneView<real> sc, 
             if (L.box_kind == OP_BOX) step_box<false, true>(L, *rec, cnt);
             else step_box<true, true>(L, *rec, cnt);
         } else if (kind == OP_SPHERE) {
-            step_sphere<true>(L, *rec, cnt);
+            step_sphere<true>(L, *rec, cnt, tie);
         } else {
-            step_other<real, kFeatAll, true>(L, rec, sc, cnt);
+            step_other<real, kFeatAll, true>(L, rec, sc, cnt, tie);
         }
     }
     double* o = out + size_t(gid) * 12;
@@ -1745,15 +1861,19 @@ static hipError_t plan_launch(Kernel kernel, int kMaxWavesPerBlock, size_t lds_b
 }
 
 // Bytes a workgroup stages in LDS: the traversal program (MIXED or slots) followed by the material table.
+// `feat` = the kernel's FEAT word: F_F32_BOX selects the MIXED program (lean family) or the COMPACT one (the others).
+static bool is_compact(uint32_t feat) { return (feat & F_F32_BOX) != 0 && (feat & ~uint32_t(F_F32_BOX | F_MATTE | F_LDS_BOXES)) != kFeatLean; }
 template <typename real>
-static size_t lds_image_bytes(const SceneView<real>& sc, bool mixed = false) {
-    const size_t program = mixed ? size_t(sc.n_units) * sizeof(MixedHead) : size_t(sc.n_slots) * sizeof(Slot<real>);
+static size_t lds_image_bytes(const SceneView<real>& sc, uint32_t feat) {
+    const size_t program = is_compact(feat) ? size_t(sc.n_units16) * sizeof(Unit16)
+                                            : ((feat & F_F32_BOX) ? size_t(sc.n_units) * sizeof(MixedHead) : size_t(sc.n_slots) * sizeof(Slot<real>));
     return program + size_t(sc.n_materials) * sizeof(MaterialRec<real>);
 }
 
 // F_LDS_BOXES kernels: the box slots, the kind nibbles (padded to 8 bytes) and the rank table.
 template <typename real>
-static size_t split_lds_bytes(const SceneView<real>& sc) {
+static size_t split_lds_bytes(const SceneView<real>& sc, uint32_t feat) {
+    if (is_compact(feat)) return size_t(sc.n_cached_boxes16) * sizeof(MixedHead) + ((size_t(sc.n_kind_words16) * 4 + 7) & ~size_t(7)) + size_t(sc.n_rank_words16) * 8;
     return size_t(sc.n_cached_boxes) * sizeof(BoxRec<real>) + ((size_t(sc.n_kind_words) * 4 + 7) & ~size_t(7)) + size_t(sc.n_rank_words) * 8;
 }
 template <typename real, uint32_t FEAT, bool COUNT, bool IN_LDS>
@@ -1763,7 +1883,7 @@ static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>* c
     const int n_items = tmap.n_tiles_local * tmap.n_chunks;
     if (n_items <= 0) return hipSuccess;
     auto kernel = rtk_render_kernel<real, FEAT, COUNT, IN_LDS>;
-    size_t lds = IN_LDS ? lds_image_bytes(sc, (FEAT & F_F32_BOX) != 0) : ((FEAT & F_LDS_BOXES) ? split_lds_bytes(sc) : 0);
+    size_t lds = IN_LDS ? lds_image_bytes(sc, FEAT) : ((FEAT & F_LDS_BOXES) ? split_lds_bytes(sc, FEAT) : 0);
     // room for the tile order behind the program?  (never at the price of a second resident workgroup's LDS)
     TileMap tm = tmap;
     tm.order_in_lds = 0;
@@ -1783,24 +1903,30 @@ static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>* c
     return hipGetLastError();
 }
 
-// The MIXED program is used whenever the upload built one (f64, sphere-only scene, fast order); variant bit 20 keeps
-// the f64 boxes instead (A/B).
+// The f32-culling-box programs are used whenever the upload built one (f64, fast order): the MIXED program of a sphere-only
+// scene, the COMPACT program of any other; variant bit 20 keeps the f64 boxes of the slot program instead (A/B, tests).
 template <typename real>
 static bool use_mixed_program(const SceneView<real>& sc, uint32_t diag) {
     return sizeof(real) == 8 && sc.program_mixed != nullptr && (diag & (1u << 20)) == 0;
 }
+template <typename real>
+static bool use_compact_program(const SceneView<real>& sc, uint32_t diag) {
+    return sizeof(real) == 8 && sc.program_compact != nullptr && (diag & (1u << 20)) == 0;
+}
 
 // Kernel instantiation for a scene: the leanest feature subset that covers it, with or without the fused slab test;
-// `mixed` = the scene has a MIXED program (f64, sphere-only, fast order) and the caller did not ask for the f64 boxes.
-static uint32_t kernel_features(uint32_t features, bool count, bool mixed) {
+// `mixed` / `compact` = the scene has that program and the caller did not ask for the f64 boxes.
+static uint32_t kernel_features(uint32_t features, bool count, bool mixed, bool compact) {
     const uint32_t fma = features & F_FMA_BOX, matte = features & F_MATTE, scene = features & ~uint32_t(F_FMA_BOX | F_MATTE);
+    const uint32_t f32box = uint32_t(F_F32_BOX);
     // counting instantiations: the MIXED program has its own (the kernel bench.py times on sphere-only scenes, with
-    // counters); everything else counts with the full-feature kernel
-    if (count) return (mixed && scene == kFeatLean) ? (kFeatLean | uint32_t(F_F32_BOX)) : (kFeatAll | fma);
-    if (scene == kFeatLean) return mixed ? (kFeatLean | uint32_t(F_F32_BOX)) : (kFeatLean | fma);
-    if ((scene & ~kFeatQuadBox) == 0) return kFeatQuadBox | matte;  // no registers to spare for o*inv at 4 waves/SIMD (it spills): exact slab test, A/B on C3 40.7 vs 42.2 ms
-    if ((scene & ~kFeatMesh) == 0) return kFeatMesh | fma | matte;
-    return kFeatAll | fma;
+    // counters), the COMPACT program counts with the full-feature kernel on that program, everything else with the
+    // full-feature kernel on the slot program (exact boxes: these counters equal the oracle's)
+    if (count) return (mixed && scene == kFeatLean) ? (kFeatLean | f32box) : (compact ? (kFeatAll | f32box) : (kFeatAll | fma));
+    if (scene == kFeatLean) return mixed ? (kFeatLean | f32box) : (kFeatLean | fma);
+    if ((scene & ~kFeatQuadBox) == 0) return kFeatQuadBox | matte | (compact ? f32box : 0u);  // slot program: no registers to spare for o*inv at 4 waves/SIMD (it spills): exact slab test, A/B on C3 40.7 vs 42.2 ms
+    if ((scene & ~kFeatMesh) == 0) return kFeatMesh | matte | (compact ? f32box : fma);
+    return kFeatAll | (compact ? f32box : fma);
 }
 
 // Which instantiation a launch uses -- decided in ONE place, for the launcher and for rtk_kernel_name alike.
@@ -1811,17 +1937,29 @@ struct KernelChoice {
 template <typename real>
 static KernelChoice choose_kernel(const SceneView<real>& sc, uint32_t features, bool count, bool allow_lds, uint32_t diag) {
     const bool mixed = use_mixed_program(sc, diag);
+    bool compact = use_compact_program(sc, diag);
+    if (compact) {
+        // Full-feature scenes whose COMPACT program does not fit LDS stay on the slot program: their coordinates run into the
+        // thousands (book-2: a fog boundary of radius 5000), the 2^-19 x extent margin then exceeds the thickness of a quad's own
+        // box and the t_min that keeps a ray off the surface it leaves, every such ray re-enters that box (+55 % quad tests on
+        // C5) and the boxes-in-LDS kernel on the COMPACT program is slower than the all-in-memory slot kernel (714 vs 838 Msamples/s)
+        const uint32_t scene_bits = features & ~uint32_t(F_FMA_BOX | F_MATTE);
+        const bool full_family = (scene_bits & ~kFeatQuadBox) != 0 && (scene_bits & ~kFeatMesh) != 0;
+        const size_t bytes = size_t(sc.n_units16) * sizeof(Unit16) + size_t(sc.n_materials) * sizeof(MaterialRec<real>);
+        if (full_family && !(allow_lds && bytes <= size_t(kLdsBytesPerCU))) compact = false;
+    }
     // the matte variants pay off in f64 only (C3: f64 34.8 -> 31.9 ms, f32 26.6 -> 36.5 ms at one more wave per SIMD)
-    KernelChoice k{kernel_features(sizeof(real) == 8 ? features : (features & ~uint32_t(F_MATTE)), count, mixed), count, false};
+    KernelChoice k{kernel_features(sizeof(real) == 8 ? features : (features & ~uint32_t(F_MATTE)), count, mixed, compact), count, false};
     const uint32_t scene = k.feat & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE);
-    const bool fits = allow_lds && lds_image_bytes(sc, (k.feat & F_F32_BOX) != 0) <= size_t(kLdsBytesPerCU);
+    const bool fits = allow_lds && lds_image_bytes(sc, k.feat) <= size_t(kLdsBytesPerCU);
     if (count) {  // counting builds: only the MIXED one stages its program (it is the timed kernel with counters)
-        k.in_lds = fits && (k.feat & F_F32_BOX) != 0;
+        k.in_lds = fits && (k.feat & F_F32_BOX) != 0 && !is_compact(k.feat);
         return k;
     }
     k.in_lds = fits;
     // a program larger than LDS whose box records are not: the boxes-in-LDS kernel (mesh and full-feature families)
-    if (!fits && sc.box_cache != nullptr && (scene == kFeatMesh || scene == kFeatAll) && (diag & (1u << 21)) == 0) k.feat |= uint32_t(F_LDS_BOXES);
+    const bool has_cache = is_compact(k.feat) ? sc.box_cache16 != nullptr : sc.box_cache != nullptr;
+    if (!fits && has_cache && (scene == kFeatMesh || scene == kFeatAll) && (diag & (1u << 21)) == 0) k.feat |= uint32_t(F_LDS_BOXES);
     return k;
 }
 
@@ -1833,13 +1971,16 @@ static hipError_t launch_feat(const KernelChoice& k, const SceneView<real>& sc, 
     if constexpr ((FEAT & ~uint32_t(F_FMA_BOX)) == kFeatAll) {
         if (k.count) RTK_GO(FEAT, true, false);
     }
-    if constexpr ((FEAT & F_F32_BOX) != 0) {  // the timed sphere-scene kernel with work counters: same program, same steps, same LDS staging
+    if constexpr (FEAT == (kFeatLean | uint32_t(F_F32_BOX))) {  // the timed sphere-scene kernel with work counters: same program, same steps, same LDS staging
         if (k.count) {
             if (k.in_lds) RTK_GO(FEAT, true, true);
             RTK_GO(FEAT, true, false);
         }
     }
-    if constexpr ((FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatMesh || (FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatAll) {
+    if constexpr (FEAT == (kFeatAll | uint32_t(F_F32_BOX))) {  // work counters on the COMPACT program (any family's scene)
+        if (k.count) RTK_GO(FEAT, true, false);
+    }
+    if constexpr ((FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE)) == kFeatMesh || (FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE)) == kFeatAll) {
         if (k.feat & F_LDS_BOXES) RTK_GO(FEAT | uint32_t(F_LDS_BOXES), false, false);
     }
     if (k.in_lds) RTK_GO(FEAT, false, true);
@@ -1864,13 +2005,26 @@ hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>* cam, 
         RTK_LAUNCH_CASE(kFeatMesh | F_FMA_BOX)
         RTK_LAUNCH_CASE(kFeatMesh | F_MATTE)
         RTK_LAUNCH_CASE(kFeatMesh | F_FMA_BOX | F_MATTE)
-        case kFeatLean | F_F32_BOX:
-            if constexpr (sizeof(real) == 8)
-                return launch_feat<real, kFeatLean | F_F32_BOX>(k, sc, cam, tmap, seed, diag, partial, counters, tile_counter, tile_order, tile_cost, stream);
-            break;
+#define RTK_LAUNCH_CASE_F64(F) \
+    case F:                      \
+        if constexpr (sizeof(real) == 8) return launch_feat<real, F>(k, sc, cam, tmap, seed, diag, partial, counters, tile_counter, tile_order, tile_cost, stream); \
+        break;
+        RTK_LAUNCH_CASE_F64(kFeatLean | F_F32_BOX)
+        RTK_LAUNCH_CASE_F64(kFeatQuadBox | F_F32_BOX)
+        RTK_LAUNCH_CASE_F64(kFeatQuadBox | F_MATTE | F_F32_BOX)
+        RTK_LAUNCH_CASE_F64(kFeatMesh | F_F32_BOX)
+        RTK_LAUNCH_CASE_F64(kFeatMesh | F_MATTE | F_F32_BOX)
 #endif
         RTK_LAUNCH_CASE(kFeatAll)
         RTK_LAUNCH_CASE(kFeatAll | F_FMA_BOX)
+#ifndef RTK_LAUNCH_CASE_F64
+#define RTK_LAUNCH_CASE_F64(F) \
+    case F:                      \
+        if constexpr (sizeof(real) == 8) return launch_feat<real, F>(k, sc, cam, tmap, seed, diag, partial, counters, tile_counter, tile_order, tile_cost, stream); \
+        break;
+#endif
+        RTK_LAUNCH_CASE_F64(kFeatAll | F_F32_BOX)
+#undef RTK_LAUNCH_CASE_F64
     }
 #undef RTK_LAUNCH_CASE
     return hipErrorInvalidValue;

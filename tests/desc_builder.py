@@ -78,6 +78,7 @@ class DescBuilder:
 
     def __init__(self):
         self.nodes, self.children, self.spheres, self.quads, self.translates, self.rotates, self.media = [], [], [], [], [], [], []
+        self.triangles = []
         self.materials, self.textures = [], []
 
     def _node(self, kind, a=0, b=0, c=0):
@@ -117,6 +118,21 @@ class DescBuilder:
         self.quads.append(Quad(Vec3(*Q), Vec3(*u), Vec3(*v), Vec3(*w), Vec3(*normal), _dot(normal, Q), material, 0))
         return self._node(NODE_QUAD, len(self.quads) - 1)
 
+    def triangle(self, p0, p1, p2, material, uvs=((0.0, 0.0), (1.0, 0.0), (0.0, 1.0))):
+        e1 = tuple(p1[k] - p0[k] for k in range(3))          # triangle.h:21-23: n = cross(p1 - p0, p2 - p0), normal = unit_vector(n)
+        e2 = tuple(p2[k] - p0[k] for k in range(3))
+        n = _cross(e1, e2)
+        length = math.sqrt(_dot(n, n))
+        normal = tuple((1 / length) * c for c in n)
+        f2 = C.c_float * 2
+        self.triangles.append(Triangle(Vec3(*p0), Vec3(*p1), Vec3(*p2), Vec3(*normal), f2(*uvs[0]), f2(*uvs[1]), f2(*uvs[2]), material, 0))
+        return self._node(NODE_TRIANGLE, len(self.triangles) - 1)
+
+    def rank(self, node, rank):
+        """rtk_node.c of a primitive node: 1 + its rank in the reference's visiting order (what rtk_scene_optimize records)."""
+        self.nodes[node].c = rank
+        return node
+
     def list(self, members):
         first = len(self.children)
         self.children.extend(members)
@@ -142,11 +158,12 @@ class BuiltDesc:
             return a
         self._keep = dict(nodes=arr(Node, b.nodes), children=(C.c_int32 * max(1, len(b.children)))(*b.children), spheres=arr(Sphere, b.spheres),
                           quads=arr(Quad, b.quads), translates=arr(Translate, b.translates), rotates=arr(RotateY, b.rotates), media=arr(Medium, b.media),
-                          materials=arr(Material, b.materials), textures=arr(Texture, b.textures), tris=arr(Triangle, []), boxes=arr(Aabb, []))
+                          materials=arr(Material, b.materials), textures=arr(Texture, b.textures), tris=arr(Triangle, b.triangles), boxes=arr(Aabb, []))
         k = self._keep
         d = SceneDesc()
         d.abi_version, d.root = 1, root
         d.n_nodes, d.n_list_children, d.n_spheres, d.n_quads = len(b.nodes), len(b.children), len(b.spheres), len(b.quads)
+        d.n_triangles = len(b.triangles)
         d.n_translates, d.n_rotates, d.n_media, d.n_materials, d.n_textures = len(b.translates), len(b.rotates), len(b.media), len(b.materials), len(b.textures)
         d.nodes, d.list_children, d.spheres, d.quads = k["nodes"], k["children"], k["spheres"], k["quads"]
         d.triangles, d.bvh_boxes, d.translates, d.rotates = k["tris"], k["boxes"], k["translates"], k["rotates"]

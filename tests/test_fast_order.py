@@ -75,7 +75,9 @@ def test_fast_order_keeps_the_scene_and_the_image(rt, orc, case):
     has_media = DescHead.from_address(scene.desc_ptr).n_media > 0
     has_tris = any(k == NODE_TRI for (k, _, _) in reachable_primitives(scene.desc_ptr))
     assert fast.info["has_media"] == has_media and fast.info["has_triangles"] == has_tris
-    assert fast.exact == (not has_media and not has_tris)
+    # exact = bit-identical to the reference order: closest hits are preserved and exact ties follow the reference's ranks;
+    # only a medium (RNG draws inside hit()) breaks it.  Triangle scenes are flagged separately (float determinant caveat).
+    assert fast.exact == (not has_media)
 
     ref, ref8, ref_cnt = orc.render(scene.desc_ptr, cam, RENDER_SEED, 4)
     got, got8, got_cnt = orc.render(fast.desc_ptr, cam, RENDER_SEED, 4)

@@ -14,7 +14,7 @@ import pytest
 from tests.desc_builder import DescBuilder
 
 
-def random_scene(seed):
+def random_scene(seed, triangles=False):
     rnd = random.Random(seed)
     b = DescBuilder()
     mats = [b.lambertian((rnd.random(), rnd.random(), rnd.random())) for _ in range(3)]
@@ -29,9 +29,13 @@ def random_scene(seed):
         q = (rnd.uniform(-4, 3), rnd.uniform(-1, 2), rnd.uniform(-8, -3))
         u = (rnd.uniform(0.3, 1.5), rnd.uniform(-0.3, 0.3), rnd.uniform(-0.5, 0.5))
         v = (rnd.uniform(-0.3, 0.3), rnd.uniform(0.3, 1.5), rnd.uniform(-0.5, 0.5))
+        if triangles and rnd.random() < 0.5:   # a triangle on the same three corners (triangle.h: float determinant and barycentrics)
+            return b.triangle(q, tuple(q[k] + u[k] for k in range(3)), tuple(q[k] + v[k] for k in range(3)), m)
         return b.quad(q, u, v, m)
 
     top = [b.sphere((0, -101, -5), 100.0, mats[0])]           # a ground sphere: one huge box among small ones
+    if triangles:                                             # at least one triangle whatever the draws
+        top.append(b.triangle((-1.0, -0.5, -4.0), (1.0, -0.5, -4.5), (0.0, 1.2, -4.2), mats[1], ((0.1, 0.2), (0.9, 0.1), (0.5, 0.8))))
     for _ in range(rnd.randint(6, 14)):
         top.append(prim())
     for _ in range(rnd.randint(1, 3)):                        # instances of small sub-lists
@@ -69,6 +73,23 @@ def test_random_soups_render_identically_in_the_fast_order(rt, orc, seed):
             assert gc[k] == rc[k], k
         assert gc["box_tests"] > 0 and gc["sphere_tests"] + gc["quad_tests"] < rc["sphere_tests"] + rc["quad_tests"]
     assert ref.std() > 0.01   # the camera actually sees the soup
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_soups_with_triangles_render_identically_in_the_fast_order(rt, orc, seed):
+    """The same with triangles among the primitives (triangle.h:65-113: float determinant and barycentrics): bit-identical
+    again -- `exact` is claimed for triangle scenes too now that ties follow the reference's ranks."""
+    scene = random_scene(3000 + seed, triangles=True)
+    cam = look_at_camera(rt)
+    ref, ref8, rc = orc.render(scene.desc_ptr, cam, 7, 4)
+    assert rc["triangle_tests"] > 0
+    for eye in (cam.center, None):
+        fast = rt.FastOrderScene(scene, eye)
+        assert fast.exact and fast.info["has_triangles"]
+        got, got8, gc = orc.render(fast.desc_ptr, cam, 7, 4)
+        assert np.array_equal(got, ref) and np.array_equal(got8, ref8), f"seed {seed}: max diff {np.abs(got - ref).max()}"
+        for k in ("segments", "surface_hits", "rng_draws"):
+            assert gc[k] == rc[k], k
 
 
 def test_degenerate_scene_of_coincident_spheres_is_handled(rt, orc):

@@ -30,16 +30,19 @@ def rmse(a, b):
     return float(np.sqrt(np.mean((a - b) ** 2)))
 
 
-def _assert_culling_counters(got, exact):
+def _assert_culling_counters(got, exact, slack=0.03):
     """Work counters of a kernel that culls with CONSERVATIVE f32 boxes (the MIXED program) against the exact counters
     of the same hierarchy (oracle / f64-box kernel): everything a closest hit determines -- samples, segments, surface
     interactions, RNG draws -- is an equal integer; box and primitive tests can only be MORE (an enlarged box admits a
     superset of rays, and an extra primitive test never produces a hit), by about one per cent (C2 at full size: +0.66 %
-    box tests, +1.03 % sphere tests -- the 2^-19 x extent margin is 1 % of a radius-0.2 sphere's box)."""
-    for key in ("samples", "segments", "surface_hits", "rng_draws", "quad_tests", "triangle_tests", "xform_enters", "medium_tests", "noise_calls", "texel_fetches"):
+    box tests, +1.03 % sphere tests -- the 2^-19 x extent margin is 1 % of a radius-0.2 sphere's box).  `slack`: scenes whose
+    coordinates run into the hundreds (the Cornell box: extent 2 600, margin 0.005) need more -- there the margin exceeds the
+    1e-4 thickness of a quad's own box (aabb.h:98-105) and the t_min = 0.001 that keeps a ray from re-hitting the surface it
+    leaves (Camera.txt:211), so every ray leaving a wall enters that wall's box again (+7 % box tests, +15 % quad tests)."""
+    for key in ("samples", "segments", "surface_hits", "rng_draws", "noise_calls", "texel_fetches"):
         assert got[key] == exact[key], key
-    for key in ("box_tests", "sphere_tests"):
-        assert exact[key] <= got[key] <= exact[key] * 1.02 + 8, (key, got[key], exact[key])
+    for key in ("box_tests", "sphere_tests", "quad_tests", "triangle_tests", "xform_enters", "medium_tests"):
+        assert exact[key] <= got[key] <= exact[key] * (1.0 + slack) + 16, (key, got[key], exact[key])
 
 
 @pytest.fixture(scope="module")
@@ -365,17 +368,22 @@ def test_fast_order_on_the_device(rt, orc, renderer, scenes, case):
     info = renderer.upload_fast(scene, cam.center)
     assert info["exact"] == fast.exact
     feat = int(renderer.kernel_name().split(",")[1].strip().rstrip("u"))
-    # fused slab test / MIXED program (sphere-only scenes) / the quad-box subset kernel keeps the exact test (512 = its matte variant)
-    assert (feat & 128) or feat == 256 or (feat & ~512) == 69
+    # every f64 kernel of the fast order culls with f32 boxes (F_F32_BOX = 256): the MIXED program of sphere-only scenes
+    # (feat == 256) or the COMPACT program of the other families; variant bit 20 keeps the f64 boxes of the slot program
+    assert (feat & 256) or name == "book2_final"     # (a full-feature scene whose COMPACT program does not fit LDS stays on the slot program)
+    slot_feat = int(renderer.kernel_name(variant=1 << 20).split(",")[1].strip().rstrip("u"))
+    assert not (slot_feat & 256) and ((slot_feat & 128) or (slot_feat & ~(512 | 1024)) == 69)
     fused, fused8, fcnt = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, count=True)
     fused_fast, _, _ = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64)
     assert np.array_equal(fused, gpu) and np.array_equal(fused8, gpu8) and np.array_equal(fused_fast, gpu)
-    if feat == 256:   # MIXED program: `count=True` ran the counting build of the F_F32_BOX kernel itself
-        _assert_culling_counters(fcnt, counters)
-        _, _, exact_cnt = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, count=True, variant=1 << 20)   # f64 boxes
-        assert exact_cnt == counters
-    else:
-        assert fcnt == counters
+    # `count=True` ran a counting build on the f32-box program (the MIXED kernel's own; the full-feature kernel on a COMPACT
+    # program): conservative culling -> a tight superset of the oracle's tests, equal closest-hit counters
+    _assert_culling_counters(fcnt, counters, slack=0.25 if name.startswith("cornell") or name == "material_zoo" else (0.12 if "mesh" in name else 0.03))
+    slot, slot8, exact_cnt = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, count=True, variant=1 << 20)   # f64 boxes
+    assert exact_cnt == counters and np.array_equal(slot, gpu) and np.array_equal(slot8, gpu8)
+    slot_fast, _, _ = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, variant=1 << 20)
+    in_global, _, _ = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, variant=1)
+    assert np.array_equal(slot_fast, gpu) and np.array_equal(in_global, gpu)
     if not fast.info["has_media"]:
         renderer.upload(scene)
         base, base8, bcnt = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, count=True)
@@ -487,22 +495,27 @@ def test_mixed_program_moving_spheres_and_far_cameras(rt, orc, renderer):
     assert got_far.std() > 0.01   # the far camera still sees the scene
 
 
-@pytest.mark.parametrize("seed", range(6))
-def test_random_soups_on_the_device(rt, orc, renderer, seed):
-    """Random sphere/quad soups with instances (tests/test_fast_order_random.py): the kernels on the flat list agree with
-    the oracle, and rtk_scene_upload_fast renders the same bytes."""
+@pytest.mark.parametrize("seed,triangles", [(s, False) for s in range(6)] + [(s, True) for s in range(6)])
+def test_random_soups_on_the_device(rt, orc, renderer, seed, triangles):
+    """Random sphere/quad(/triangle) soups with instances (tests/test_fast_order_random.py): the kernels on the flat list
+    agree with the oracle, and rtk_scene_upload_fast (COMPACT program: f32 culling boxes also under the instance transforms,
+    ties by reference rank) renders the same bytes."""
     from tests.test_fast_order_random import look_at_camera, random_scene
 
-    scene = random_scene(2000 + seed)
+    scene = random_scene(2000 + seed, triangles=triangles)
     cam = look_at_camera(rt)
     ref, ref8, ocnt = orc.render(scene.desc_ptr, cam, 7, 4)
     renderer.upload(scene)
     gpu, gpu8, cnt = renderer.render_host(cam, seed=7, count=True)
     assert rmse(gpu, ref) < F64_RMSE_BOUND and np.array_equal(gpu8, ref8) and cnt == ocnt
     info = renderer.upload_fast(scene, cam.center)
-    assert info["exact"]
+    assert info["exact"] and int(renderer.kernel_name().split(",")[1].strip(" u")) & 256
     fast, fast8, _ = renderer.render_host(cam, seed=7)
     assert np.array_equal(fast, gpu) and np.array_equal(fast8, gpu8)
+    fast_global, _, fcnt = renderer.render_host(cam, seed=7, variant=1, count=True)
+    assert np.array_equal(fast_global, gpu)
+    for key in ("samples", "segments", "surface_hits", "rng_draws"):
+        assert fcnt[key] == cnt[key], key
 
 
 def test_cpp_camera_render_through_the_drop_in_api(rt, tmp_path):
@@ -585,13 +598,17 @@ def test_boxes_in_lds_kernel_for_programs_larger_than_lds(rt, orc, renderer, sce
     cam = scene.camera(64, 36, 4, 10)
     for fast in (False, True):
         renderer.upload_fast(scene, cam.center) if fast else renderer.upload(scene)
-        assert (rt.hip_lib().rtk_kernel_name is not None)
-        with_boxes, plain = renderer.kernel_name(), renderer.kernel_name(variant=1 << 21)
+        # fast order: the COMPACT program (151 KB) fits LDS whole; its slot program (variant bit 20) does not
+        slot = (1 << 20) if fast else 0
+        if fast:
+            assert renderer.kernel_name().endswith("false, true>") and int(renderer.kernel_name().split(",")[1].strip(" u")) & 256
+        with_boxes, plain = renderer.kernel_name(variant=slot), renderer.kernel_name(variant=slot | (1 << 21))
         assert "false, false" in with_boxes and int(with_boxes.split(",")[1].strip(" u")) == int(plain.split(",")[1].strip(" u")) | 1024
-        a, a8, _ = renderer.render_host(cam)
-        b, b8, _ = renderer.render_host(cam, variant=1 << 21)
+        a, a8, _ = renderer.render_host(cam, variant=slot)
+        b, b8, _ = renderer.render_host(cam, variant=slot | (1 << 21))
         c, c8, _ = renderer.render_host(cam, count=True)
-        assert np.array_equal(a, b) and np.array_equal(a8, b8) and np.array_equal(a, c)
+        d, d8, _ = renderer.render_host(cam)
+        assert np.array_equal(a, b) and np.array_equal(a8, b8) and np.array_equal(a, c) and np.array_equal(a, d)
     renderer.upload(scene)
     ref, ref8, _ = orc.render(scene.desc_ptr, cam, RENDER_SEED, 8)
     a, a8, _ = renderer.render_host(cam)

@@ -66,6 +66,7 @@ using Chain = std::vector<ChainStep>;
 struct Program {
     std::vector<Op> ops;
     std::vector<uint32_t> ranks;  // parallel to ops: rtk_node.c of a primitive op (1 + reference visiting rank; 0 = none)
+    std::vector<uint32_t> extra;  // parallel to ops: OP_MED_SPHERE -> index of the boundary sphere
     std::vector<Chain> chains;
     std::map<Chain, uint32_t> chain_ids;
     size_t last_label = size_t(-1);  // op index some skip link points at
@@ -101,6 +102,7 @@ struct Compiler {
     uint32_t push(uint32_t kind, uint32_t payload, uint32_t aux, uint32_t rank = 0) {
         prog.ops.push_back(Op{make_op(kind, payload), aux});
         prog.ranks.push_back(rank);
+        prog.extra.push_back(0);
         return uint32_t(prog.ops.size()) - 1;
     }
     void label_here() { prog.last_label = prog.ops.size(); }
@@ -172,6 +174,15 @@ struct Compiler {
                 if (n.a < 0 || n.a >= sc.n_media) return bad(RTK_ERR_INVALID, "medium index out of range");
                 if (in_medium) return bad(RTK_ERR_UNSUPPORTED, "constant_medium inside the boundary of another constant_medium");
                 prog.features |= F_MEDIA;
+                if (n.b >= 0 && n.b < sc.n_nodes && sc.nodes[n.b].kind == RTK_NODE_SPHERE && sc.nodes[n.b].a >= 0 && sc.nodes[n.b].a < sc.n_spheres && !getenv("RTK_NO_MED_SPHERE")) {
+                    const rtk_sphere& s = sc.spheres[sc.nodes[n.b].a];
+                    if (s.center_dir.x == 0 && s.center_dir.y == 0 && s.center_dir.z == 0) {  // a stationary sphere as the boundary: the fused record
+                        const uint32_t at = push(OP_MED_SPHERE, uint32_t(n.a), cid);
+                        prog.extra[at] = uint32_t(sc.nodes[n.b].a);
+                        prog.n_primitive_ops++;
+                        return true;
+                    }
+                }
                 push(OP_MED_BEGIN, uint32_t(n.a), 0);
                 if (!emit(n.b, chain, true, depth + 1)) return false;
                 uint32_t mid = push(OP_MED_MID, uint32_t(n.a), 0);
@@ -454,6 +465,14 @@ static void build_compact_program(const rtk_scene_desc& sc, const Program& prog,
                 head->d[0] = sc.media[payload].neg_inv_density;
                 with_material(sc.media[payload].material);
                 break;
+            case OP_MED_SPHERE: {
+                const rtk_sphere& s = sc.spheres[prog.extra[i]];
+                head->d[0] = s.center0.x; head->d[1] = s.center0.y; head->d[2] = s.center0.z;
+                more[0] = s.radius;
+                more[1] = sc.media[payload].neg_inv_density;
+                with_material(sc.media[payload].material);
+                break;
+            }
             default: break;
         }
     }
@@ -530,6 +549,13 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
                 rec->v[0] = real(sc.media[payload].neg_inv_density);
                 with_material(sc.media[payload].material);
                 break;
+            case OP_MED_SPHERE: {
+                const rtk_sphere& s = sc.spheres[prog.extra[i]];
+                const double vals[5] = {s.center0.x, s.center0.y, s.center0.z, s.radius, sc.media[payload].neg_inv_density};
+                pack(rec, vals, 5);
+                with_material(sc.media[payload].material);
+                break;
+            }
             default: break;
         }
     }
@@ -987,6 +1013,7 @@ static int compile_scene(const rtk_scene_desc* scene, Program& prog) {
     if (prog.n_primitive_ops == 0) return fail(RTK_ERR_INVALID, "rtk_scene_upload: no primitive reachable from the root");
     prog.ops.push_back(Op{make_op(OP_END, 0), 0});
     prog.ranks.push_back(0);
+    prog.extra.push_back(0);
     return RTK_OK;
 }
 

@@ -44,6 +44,12 @@ enum OpKind : uint32_t {
     OP_MED_MID = 7,    // 1 slot : payload = medium index, aux = pc after the matching OP_MED_END
     OP_MED_END = 8,    // 1 slot : v[0] = neg_inv_density; payload = medium index, aux = chain | material << 8
     OP_SPHERE_MOVING = 9,  // 2 slots: as OP_SPHERE, then v = dx,dy,dz (center2 - center1)
+    // constant_medium::hit whose boundary is one stationary sphere (both media of the book-2 scene: the fog inside the glass
+    // ball and the global fog of radius 5000, main.cpp:305-309), as ONE record instead of the five-step bracket
+    // OP_MED_BEGIN . OP_SPHERE . OP_MED_MID . OP_SPHERE . OP_MED_END: the same two sphere::hit calls with the same
+    // intervals, the same clamping, the same single random_double() (constant_medium.h:20-53) -- four scheduler rounds
+    // fewer per medium test, and no query state to park meanwhile.
+    OP_MED_SPHERE = 10,    // 1 slot : v = cx,cy,cz,radius,neg_inv_density; payload = medium index, aux = chain | material << 8
     OP_DEAD = 15           // never in a program: the kernel's marker for a lane that owns no pixel
 };
 
@@ -104,12 +110,13 @@ inline constexpr int mixed_units(uint32_t kind) { return kind == OP_SPHERE ? 2 :
 //   OP_SPHERE_MOVING  5 units: centre(3), radius, 1/radius, centre2 - centre1 (3)
 //   OP_QUAD           9 units: n(3), D, Q(3), w(3), v(3), u(3)
 //   OP_TRI            5 units: e2(3), e1(3), p0(3)
+//   OP_MED_SPHERE     3 units: centre(3), radius, neg_inv_density
 //   OP_CHAIN, OP_MED_BEGIN, OP_MED_MID, OP_MED_END (element 0 = neg_inv_density), OP_END: 2 units
 struct alignas(16) Unit16 {
     uint32_t w[4];
 };
 inline constexpr int compact_units(uint32_t kind) {
-    return kind == OP_SPHERE ? 3 : (kind == OP_SPHERE_MOVING ? 5 : (kind == OP_QUAD ? 9 : (kind == OP_TRI ? 5 : 2)));
+    return (kind == OP_SPHERE || kind == OP_MED_SPHERE) ? 3 : (kind == OP_SPHERE_MOVING ? 5 : (kind == OP_QUAD ? 9 : (kind == OP_TRI ? 5 : 2)));
 }
 
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;

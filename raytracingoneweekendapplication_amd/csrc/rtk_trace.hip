@@ -634,6 +634,31 @@ RTK_DEV void step_other(Lane<real>& L, const Rec* __restrict__ rec, const SceneV
             L.oi = L.o * L.inv;
         }
         L.pc += rec_units<real>(rec, kind);
+    } else if ((FEAT & F_MEDIA) && kind == OP_MED_SPHERE) {
+        // constant_medium::hit (constant_medium.h:20-53) with a stationary sphere as the boundary, in one step: the two
+        // boundary->hit calls (universe, then (t1 + 0.0001, inf)) are two sphere::hit calls on the same sphere and ray, then the
+        // clamp to the ray's interval, one random_double() and the scatter distance.  The lane's own interval and closest hit
+        // are only touched by the final acceptance, so nothing is parked meanwhile.
+        cnt.inc(C_MEDIUM);
+        const V3<real> cc = packed3<real, 0>(rec);
+        const real radius = packed<real, 3>(rec);
+        real r1, r2;
+        cnt.inc(C_SPHERE);
+        if (sphere_root(cc, radius, ray_o<XF>(L), ray_d<XF>(L), L.a, L.inv_a, -real_inf<real>(), real_inf<real>(), r1)) {  // constant_medium.h:23
+            cnt.inc(C_SPHERE);
+            if (sphere_root(cc, radius, ray_o<XF>(L), ray_d<XF>(L), L.a, L.inv_a, r1 + real(0.0001), real_inf<real>(), r2)) {  // constant_medium.h:26
+                if (r1 < L.tmin) r1 = L.tmin;
+                if (r2 > L.best_t) r2 = L.best_t;
+                if (r1 < r2) {
+                    if (r1 < real(0)) r1 = real(0);
+                    const real ray_length = rt_sqrt(L.a);
+                    const real inside = (r2 - r1) * ray_length;
+                    const real hit_distance = packed<real, 4>(rec) * rt_log(rnd<real>(L.rng, cnt));
+                    if (!(hit_distance > inside)) take_hit<MIXED>(L, r1 + hit_distance / ray_length);
+                }
+            }
+        }
+        L.pc += rec_units<real>(rec, kind);
     } else if ((FEAT & F_MEDIA) && kind == OP_MED_BEGIN) {
         cnt.inc(C_MEDIUM);
         L.sv_tmin = L.tmin;

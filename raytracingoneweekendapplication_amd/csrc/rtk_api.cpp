@@ -1086,6 +1086,7 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
     tm.compact = compact_out ? 1 : 0;
     tm.order_in_lds = 0;
     tm.order_lds_offset = 0;
+    tm.mats_lds_offset = 0;
     // Split every pixel's samples into chunks of 8 (at most 64 chunks) so that no lane is stuck with a whole
     // heavy pixel: a glass pixel's samples cost ~0.2 ms each, and the largest (pixel, chunk) bounds the end of
     // the frame whatever the GPU count.  Measured on C2 (v16 kernel time, N = 1 / one of 8 shards): 4-sample chunks

@@ -260,6 +260,8 @@ struct TileMap {  // which tiles this launch renders and where the pixels go
     int16_t chunk_start[kMaxChunks + 1];
     // set by the launcher: the tile hand-out order is staged in LDS at this byte offset of the dynamic segment
     int32_t order_in_lds, order_lds_offset;
+    // F_LDS_BOXES kernels: byte offset of the material table staged behind the box tables (0 = materials stay in memory)
+    int32_t mats_lds_offset;
 };
 
 // Indices into the uint64 work-counter block (same order as rtk_work_counters).

@@ -1142,6 +1142,9 @@ RTK_DEV void store_partial(real* __restrict__ partial, int item, int pix, V3<rea
     base[128] = sum.z;
 }
 
+#ifndef RTK_SPLIT_MATERIALS_IN_LDS
+#define RTK_SPLIT_MATERIALS_IN_LDS 1
+#endif
 #ifndef RTK_THREADS_ALL_F64
 #define RTK_THREADS_ALL_F64 512   // workgroup bound of the full-feature f64 kernel (A/B builds: 768 = 3 waves per SIMD, 1024 = 4)
 #endif
@@ -1224,6 +1227,16 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
         for (int k = threadIdx.x; k < n_kind_words; k += blockDim.x) kdst[k] = kind_words[k];
         uint2* rdst = reinterpret_cast<uint2*>(lds_program + box_bytes + ((size_t(n_kind_words) * 4 + 7) & ~size_t(7)));
         for (int k = threadIdx.x; k < n_rank_words; k += blockDim.x) rdst[k] = box_rank[k];
+#if RTK_SPLIT_MATERIALS_IN_LDS
+        // ... and the material table behind them when the launcher found room (tmap.mats_lds_offset > 0): every shade step reads it
+        if (tmap.mats_lds_offset > 0) {
+            const int n_mat16 = sc.n_materials * int(sizeof(MaterialRec<real>) / 16);
+            const uint4* __restrict__ msrc = reinterpret_cast<const uint4*>(sc.materials);
+            uint4* mdst = reinterpret_cast<uint4*>(lds_program + tmap.mats_lds_offset);
+            for (int k = threadIdx.x; k < n_mat16; k += blockDim.x) mdst[k] = msrc[k];
+            mats = reinterpret_cast<const MaterialRec<real>*>(lds_program + tmap.mats_lds_offset);
+        }
+#endif
         __syncthreads();
         lds_boxes = reinterpret_cast<const BoxCacheRec*>(lds_program);
         lds_kinds = kdst;
@@ -1459,6 +1472,8 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             uint32_t k = kind;
             // the record at L.pc -> cur, its kind -> k.  SPLIT: the kind comes from the LDS nibble table and only boxes are
             // fetched (from the LDS copy); a primitive's record is read from memory by the step that tests it
+            // (tried on C5: requesting a sphere's record from memory already here, when a lane lands on it -- 770 vs 839 Msamples/s:
+            // `cur` is one set of registers for the whole wave, so the next box step waits for that load all the same)
             auto fetch = [&]() {
                 if constexpr (SPLIT) {
                     k = kind_of(L.pc);
@@ -1909,8 +1924,17 @@ static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>* c
     if (n_items <= 0) return hipSuccess;
     auto kernel = rtk_render_kernel<real, FEAT, COUNT, IN_LDS>;
     size_t lds = IN_LDS ? lds_image_bytes(sc, FEAT) : ((FEAT & F_LDS_BOXES) ? split_lds_bytes(sc, FEAT) : 0);
-    // room for the tile order behind the program?  (never at the price of a second resident workgroup's LDS)
     TileMap tm = tmap;
+    tm.mats_lds_offset = 0;
+    if constexpr ((FEAT & F_LDS_BOXES) != 0) {  // boxes-in-LDS kernels: the material table too, if it is small and there is room
+        const size_t mat_bytes = size_t(sc.n_materials) * sizeof(MaterialRec<real>);
+        const size_t at = (lds + 15) & ~size_t(15);
+        if (RTK_SPLIT_MATERIALS_IN_LDS && mat_bytes <= 16 * 1024 && at + mat_bytes + 64 <= size_t(kLdsBytesPerCU)) {
+            tm.mats_lds_offset = int32_t(at);
+            lds = at + mat_bytes;
+        }
+    }
+    // room for the tile order behind the program?  (never at the price of a second resident workgroup's LDS)
     tm.order_in_lds = 0;
     tm.order_lds_offset = int32_t((lds + 15) & ~size_t(15));
     const size_t order_bytes = size_t(tmap.n_tiles_local) * sizeof(int32_t);

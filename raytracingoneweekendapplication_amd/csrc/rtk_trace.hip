@@ -296,7 +296,9 @@ RTK_DEV bool tie_inclusive_wins(const uint32_t* __restrict__ ranks, uint32_t pc,
 }
 
 // sphere::hit up to the accepted root (sphere.h:32-49); cc = center.at(r.time()); a = d.d, inv_a = 1/a.
-// TIE kernels: a root that EQUALS tmax is offered to `wins_tie()` (tie_sphere_wins on the lane's state).
+// TIE kernels: the interval test admits r == tmax as well -- the same two comparisons -- and only a root that was admitted
+// is then checked for being that tie, which `wins_tie()` (tie_sphere_wins on the lane's state) decides; a tie that loses is
+// a miss, exactly as in the reference, whose second root then lies beyond tmax.  The common path costs nothing extra.
 template <bool TIE = false, typename real, typename F>
 RTK_DEV bool sphere_root(V3<real> cc, real radius, V3<real> o, V3<real> d, real a, real inv_a, real tmin, real tmax, real& root, F&& wins_tie) {
     V3<real> oc = cc - o;
@@ -306,17 +308,17 @@ RTK_DEV bool sphere_root(V3<real> cc, real radius, V3<real> o, V3<real> d, real 
     if (disc < real(0)) return false;
     real sq = rt_sqrt(disc);
     real r = divide_by(h - sq, a, inv_a);
-    bool ok = tmin < r && r < tmax;
     if constexpr (TIE) {
-        if (r == tmax && tmin < r) ok = wins_tie();
-    }
-    if (!ok) {
-        r = divide_by(h + sq, a, inv_a);
-        ok = tmin < r && r < tmax;
-        if constexpr (TIE) {
-            if (r == tmax && tmin < r) ok = wins_tie();
+        if (!(tmin < r && r <= tmax)) {
+            r = divide_by(h + sq, a, inv_a);
+            if (!(tmin < r && r <= tmax)) return false;
         }
-        if (!ok) return false;
+        if (r == tmax && !wins_tie()) return false;
+    } else {
+        if (!(tmin < r && r < tmax)) {
+            r = divide_by(h + sq, a, inv_a);
+            if (!(tmin < r && r < tmax)) return false;
+        }
     }
     root = r;
     return true;
@@ -1272,7 +1274,11 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
     };
     // exact ties between primitives are resolved by the reference's ranks in the kernels that run re-grouped hierarchies
     // (the quad/box subset kernel serves the fast order without a flag of its own)
-    constexpr bool TIE = (FEAT & (F_FMA_BOX | F_F32_BOX)) != 0 || (FEAT & ~uint32_t(F_MATTE)) == kFeatQuadBox;
+    // f64 kernels only: the float kernels are not bit-exact against the reference anyway, and the lean one has no register to spare
+#ifndef RTK_AB_NO_TIE
+#define RTK_AB_NO_TIE 0   // tools/ab: what the tie rule costs
+#endif
+    constexpr bool TIE = !RTK_AB_NO_TIE && sizeof(real) == 8 && ((FEAT & (F_FMA_BOX | F_F32_BOX)) != 0 || (FEAT & ~uint32_t(F_MATTE)) == kFeatQuadBox);
     const TieCtx<TIE, decltype(kind_of)> tie{TIE ? (MIXED ? sc.tie_rank : sc.tie_rank_slot) : nullptr, kind_of};
     // The hand-out order of the tiles (learned from the previous frame) is staged behind the program when the host
     // found room for it (tmap.order_in_lds): a lookup per work item from LDS instead of a cold global load.

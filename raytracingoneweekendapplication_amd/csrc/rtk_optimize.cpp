@@ -45,6 +45,7 @@
 #include <limits>
 #include <new>
 #include <unordered_set>
+#include <utility>
 #include <vector>
 
 #include "rtk.h"
@@ -553,7 +554,7 @@ struct Optimizer {
 
 extern "C" {
 
-int rtk_scene_optimize(const rtk_scene_desc* scene, const rtk_optimize_opts* opts_in, rtk_scene_desc** out_scene, rtk_optimize_info* info) {
+static int optimize_once(const rtk_scene_desc* scene, const rtk_optimize_opts* opts_in, rtk_scene_desc** out_scene, rtk_optimize_info* info) {
     if (!scene || !out_scene) return RTK_ERR_INVALID;
     *out_scene = nullptr;
     if (scene->abi_version != RTK_ABI_VERSION || scene->n_nodes <= 0 || !scene->nodes || scene->root < 0 || scene->root >= scene->n_nodes) return RTK_ERR_INVALID;
@@ -619,5 +620,70 @@ int rtk_scene_optimize(const rtk_scene_desc* scene, const rtk_optimize_opts* opt
 }
 
 void rtk_scene_optimized_free(rtk_scene_desc* scene) { delete reinterpret_cast<Holder*>(scene); }
+
+// Bytes of the COMPACT traversal program (csrc/rtk_device_layout.h: 16-byte units; box 32, sphere 48, moving sphere 80,
+// triangle 80, quad 144, every other record 32) the upload would compile from `d`, materials included -- the quantity
+// that decides whether the f64 kernels can keep the whole program in one CU's LDS (160 KB).  Mirrors the compiler's walk
+// (rtk_api.cpp): a shared subtree counts once per use; a sphere-bounded medium is one 48-byte record.
+static size_t compact_program_bytes(const rtk_scene_desc& d) {
+    size_t bytes = 32 /* OP_END */ + size_t(d.n_materials) * 48;
+    std::vector<std::pair<int32_t, int>> stack{{d.root, 0}};
+    size_t guard = 0;
+    while (!stack.empty() && guard++ < (size_t(1) << 24) && bytes < (size_t(1) << 30)) {
+        const auto [node, depth] = stack.back();
+        stack.pop_back();
+        if (node < 0 || node >= d.n_nodes || depth > 4096) continue;
+        const rtk_node& n = d.nodes[node];
+        switch (n.kind) {
+            case RTK_NODE_SPHERE: {
+                const bool moving = n.a >= 0 && n.a < d.n_spheres && (d.spheres[n.a].center_dir.x != 0 || d.spheres[n.a].center_dir.y != 0 || d.spheres[n.a].center_dir.z != 0);
+                bytes += moving ? 80 : 48;
+                break;
+            }
+            case RTK_NODE_QUAD: bytes += 144; break;
+            case RTK_NODE_TRIANGLE: bytes += 80; break;
+            case RTK_NODE_LIST:
+                if (n.a >= 0 && n.b >= 0 && int64_t(n.a) + n.b <= d.n_list_children)
+                    for (int32_t k = 0; k < n.b; k++) stack.push_back({d.list_children[n.a + k], depth + 1});
+                break;
+            case RTK_NODE_BVH: bytes += 32; stack.push_back({n.a, depth + 1}); stack.push_back({n.b, depth + 1}); break;
+            case RTK_NODE_TRANSLATE: case RTK_NODE_ROTATE_Y: bytes += 64; stack.push_back({n.b, depth + 1}); break;
+            case RTK_NODE_MEDIUM: {
+                const bool sphere_bound = n.b >= 0 && n.b < d.n_nodes && d.nodes[n.b].kind == RTK_NODE_SPHERE;
+                if (sphere_bound) bytes += 48;
+                else { bytes += 96; stack.push_back({n.b, depth + 1}); stack.push_back({n.b, depth + 1}); }
+                break;
+            }
+            default: break;
+        }
+    }
+    return bytes;
+}
+
+// With opts->prim_cost_scale left at 0 ("automatic"), a scene with triangles is first re-grouped with primitive tests
+// priced 1.4x dearer -- more, tighter boxes and fewer triangle tests, which is what pays once the kernels read the
+// triangles from LDS (C4: 69.0 -> 67.0 ms) -- and that hierarchy is kept only if its COMPACT program still fits one CU's
+// LDS: a program that must be split between LDS and memory loses far more than the better hierarchy gains (C4 at 1.6x:
+// 175 ms).  An explicit scale is honoured as given.
+int rtk_scene_optimize(const rtk_scene_desc* scene, const rtk_optimize_opts* opts_in, rtk_scene_desc** out_scene, rtk_optimize_info* info) {
+    if (!scene || !out_scene) return RTK_ERR_INVALID;
+    rtk_optimize_opts o;
+    std::memset(&o, 0, sizeof o);
+    if (opts_in) o = *opts_in;
+    if (!(o.prim_cost_scale > 0) && scene->n_triangles > 0) {
+        o.prim_cost_scale = 1.4;
+        rtk_optimize_info local;
+        if (optimize_once(scene, &o, out_scene, &local) == RTK_OK) {
+            if (compact_program_bytes(**out_scene) + 2048 <= size_t(160) * 1024) {
+                if (info) *info = local;
+                return RTK_OK;
+            }
+            rtk_scene_optimized_free(*out_scene);
+            *out_scene = nullptr;
+        }
+        o.prim_cost_scale = 0.0;
+    }
+    return optimize_once(scene, &o, out_scene, info);
+}
 
 }  // extern "C"

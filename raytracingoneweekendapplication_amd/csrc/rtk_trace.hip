@@ -1994,14 +1994,12 @@ static KernelChoice choose_kernel(const SceneView<real>& sc, uint32_t features, 
     const bool mixed = use_mixed_program(sc, diag);
     bool compact = use_compact_program(sc, diag);
     if (compact) {
-        // Full-feature scenes whose COMPACT program does not fit LDS stay on the slot program: their coordinates run into the
-        // thousands (book-2: a fog boundary of radius 5000), the 2^-19 x extent margin then exceeds the thickness of a quad's own
-        // box and the t_min that keeps a ray off the surface it leaves, every such ray re-enters that box (+55 % quad tests on
-        // C5) and the boxes-in-LDS kernel on the COMPACT program is slower than the all-in-memory slot kernel (714 vs 838 Msamples/s)
-        const uint32_t scene_bits = features & ~uint32_t(F_FMA_BOX | F_MATTE);
-        const bool full_family = (scene_bits & ~kFeatQuadBox) != 0 && (scene_bits & ~kFeatMesh) != 0;
+        // Only when it fits one CU's LDS.  A COMPACT program split between LDS (box heads) and memory (primitives) is slower
+        // than the slot program split the same way, measured: C4 with 4 494 ops 175 ms against 95 ms, C5 714 against 838
+        // Msamples/s (there the coordinates run into the thousands -- a fog boundary of radius 5000 -- and the 2^-19 x extent
+        // margin exceeds a quad's own box thickness: +55 % quad tests).
         const size_t bytes = size_t(sc.n_units16) * sizeof(Unit16) + size_t(sc.n_materials) * sizeof(MaterialRec<real>);
-        if (full_family && !(allow_lds && bytes <= size_t(kLdsBytesPerCU))) compact = false;
+        if (!(allow_lds && bytes <= size_t(kLdsBytesPerCU))) compact = false;
     }
     // the matte variants pay off in f64 only (C3: f64 34.8 -> 31.9 ms, f32 26.6 -> 36.5 ms at one more wave per SIMD)
     KernelChoice k{kernel_features(sizeof(real) == 8 ? features : (features & ~uint32_t(F_MATTE)), count, mixed, compact), count, false};
@@ -2035,8 +2033,8 @@ static hipError_t launch_feat(const KernelChoice& k, const SceneView<real>& sc, 
     if constexpr (FEAT == (kFeatAll | uint32_t(F_F32_BOX))) {  // work counters on the COMPACT program (any family's scene)
         if (k.count) RTK_GO(FEAT, true, false);
     }
-    if constexpr ((FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE)) == kFeatMesh || (FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE)) == kFeatAll) {
-        if (k.feat & F_LDS_BOXES) RTK_GO(FEAT | uint32_t(F_LDS_BOXES), false, false);
+    if constexpr ((FEAT & F_F32_BOX) == 0 && ((FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatMesh || (FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatAll)) {
+        if (k.feat & F_LDS_BOXES) RTK_GO(FEAT | uint32_t(F_LDS_BOXES), false, false);  // (slot programs only: see choose_kernel)
     }
     if (k.in_lds) RTK_GO(FEAT, false, true);
     RTK_GO(FEAT, false, false);

@@ -1275,6 +1275,23 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
     // exact ties between primitives are resolved by the reference's ranks in the kernels that run re-grouped hierarchies
     // (the quad/box subset kernel serves the fast order without a flag of its own)
     // f64 kernels only: the float kernels are not bit-exact against the reference anyway, and the lean one has no register to spare
+// Wave priorities (s_setprio) by scheduler phase.  The SIMD's instruction arbiter serves the higher priority first (then the
+// older wave); waves inside a traversal loop -- short dependent chains, an LDS round trip per step -- lose issue slots to
+// waves that are in a shade step (long independent runs of arithmetic) exactly when a stall costs them most.  Measured on
+// C2 (tools/ab, same box): no priorities 21.93-22.09 ms; box loop 1 / 2 / 3: 21.55 / 21.53 / 21.52; box 2 + sphere loop 1:
+// 21.45-21.49 (kept); raising the shade step instead: 22.5.
+#ifndef RTK_AB_BOX_PRIO
+#define RTK_AB_BOX_PRIO 2
+#endif
+#ifndef RTK_AB_PRIM_PRIO
+#define RTK_AB_PRIM_PRIO 1   // quad and triangle loops
+#endif
+#ifndef RTK_AB_SPH_PRIO
+#define RTK_AB_SPH_PRIO 1
+#endif
+#ifndef RTK_AB_SHADE_PRIO
+#define RTK_AB_SHADE_PRIO 0
+#endif
 #ifndef RTK_AB_NO_TIE
 #define RTK_AB_NO_TIE 0   // tools/ab: what the tie rule costs
 #endif
@@ -1496,6 +1513,9 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             }
             const uint32_t box_kind = L.box_kind;  // a lane with an irregular ray matches nothing here: it never steps in this loop
             int remaining;
+#if RTK_AB_BOX_PRIO
+            __builtin_amdgcn_s_setprio(RTK_AB_BOX_PRIO);
+#endif
             // Sphere tests ride along: whenever `sphere_min` lanes of the wave sit on a sphere record, they are
             // stepped here, inside the box loop, instead of waiting for the loop to drain and a vote to pick
             // them (a vote round costs about two box steps).  Those lanes then return to box records, which
@@ -1563,6 +1583,9 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                 remaining = popcount64(__ballot(k == box_kind));
                 RTK_PROF_MARK(1, 1, remaining)
             } while (remaining >= keep);
+#if RTK_AB_BOX_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         } else if (pick == W_SPHERE) {
             // A bvh leaf usually holds two spheres in a row: same amortisation, half the starters.
             const int ssel = int(diag >> 11) & 7;  // tools/: same for the sphere loop (0 = default)
@@ -1571,6 +1594,9 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             CurRec cur = head_at(L.pc);
             uint32_t k = kind;
             int remaining;
+#if RTK_AB_SPH_PRIO
+            __builtin_amdgcn_s_setprio(RTK_AB_SPH_PRIO);
+#endif
             do {
                 if (k == OP_SPHERE) {
                     if constexpr (COMPACT) step_sphere_compact<XF>(L, cur, prog + L.pc, cnt, tie);
@@ -1588,12 +1614,18 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                 remaining = popcount64(__ballot(k == OP_SPHERE));
                 RTK_PROF_MARK(2, 1, remaining)
             } while (remaining >= keep);
+#if RTK_AB_SPH_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         } else if ((FEAT & F_QUAD) && pick == W_QUAD) {
           if constexpr ((FEAT & F_QUAD) != 0) {
             // quad::hit.  A box() is six quads in a row (quad.h:86-108): stay while at least half the starters do.
             const int keep = (n_quad >> 1) > 8 ? (n_quad >> 1) : 8;
             uint32_t k = kind;
             int remaining;
+#if RTK_AB_PRIM_PRIO
+            __builtin_amdgcn_s_setprio(RTK_AB_PRIM_PRIO);
+#endif
             do {
                 if (k == OP_QUAD) {
                     hit_quad<XF, MIXED>(L, prog + L.pc, kQuadUnits, cnt, tie);
@@ -1603,6 +1635,9 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                 remaining = popcount64(__ballot(k == OP_QUAD));
                 RTK_PROF_MARK(5, 1, remaining)
             } while (remaining >= keep);
+#if RTK_AB_PRIM_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
           }
         } else if ((FEAT & F_TRI) && pick == W_TRI) {
           if constexpr ((FEAT & F_TRI) != 0) {
@@ -1610,6 +1645,9 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             const int keep = (n_tri >> 1) > 8 ? (n_tri >> 1) : 8;
             uint32_t k = kind;
             int remaining;
+#if RTK_AB_PRIM_PRIO
+            __builtin_amdgcn_s_setprio(RTK_AB_PRIM_PRIO);
+#endif
             do {
                 if (k == OP_TRI) {
                     hit_tri<XF, MIXED>(L, prog + L.pc, kTriUnits, cnt, tie);
@@ -1619,10 +1657,16 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                 remaining = popcount64(__ballot(k == OP_TRI));
                 RTK_PROF_MARK(5, 1, remaining)
             } while (remaining >= keep);
+#if RTK_AB_PRIM_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
           }
         } else if (pick == W_SHADE) {
             // 1. the body of ray_color for the lanes whose segment ended; a finished (pixel, chunk) is written out
             bool finished = false, next_sample = false, alive = false;
+#if RTK_AB_SHADE_PRIO
+            __builtin_amdgcn_s_setprio(RTK_AB_SHADE_PRIO);
+#endif
             if (kind == OP_END) {
                 alive = true;
                 const bool ended = L.depth <= 0 || shade<real, FEAT, COUNT>(L, prog, sc, mats, cam, cnt);
@@ -1678,6 +1722,9 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                 else L.pc = end_pc;
                 L.kind = kind_of(L.pc);
             }
+#if RTK_AB_SHADE_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             RTK_PROF_MARK(3, 1, n_shd)
         } else {
             if (m_oth >> lane & 1ull) {

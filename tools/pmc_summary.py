@@ -42,8 +42,18 @@ def is_timed(name):
     return short in name.replace("void ", "")
 
 
+def newest_per_pass(pattern):
+    """One file per pass directory: the most recent one (gpurun merges a new collection over an older one's files)."""
+    best = {}
+    for f in glob.glob(pattern, recursive=True):
+        key = os.path.relpath(f, out).split(os.sep)[0]
+        if key not in best or os.path.getmtime(f) > os.path.getmtime(best[key]):
+            best[key] = f
+    return list(best.values())
+
+
 vals, meta, n_disp = {}, {}, {}
-for f in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), recursive=True):
+for f in newest_per_pass(os.path.join(out, "*", "**", "*counter_collection.csv")):
     with open(f) as fh:
         rows = [r for r in csv.DictReader(fh) if is_timed(r.get("Kernel_Name", ""))]
     per_counter = {}
@@ -59,12 +69,12 @@ for f in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), recu
 
 # kernel durations from the --kernel-trace --stats run of the same command
 dur, stats_rows = [], []
-for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True):
+for f in newest_per_pass(os.path.join(out, "stats", "**", "*kernel_trace.csv")):
     with open(f) as fh:
         for r in csv.DictReader(fh):
             if is_timed(r.get("Kernel_Name", "")):
                 dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
+for f in newest_per_pass(os.path.join(out, "stats", "**", "*kernel_stats.csv")):
     shutil.copy(f, os.path.join(ROOT, "profiles", f"{rnd}_kernel_stats_{cfg}.csv"))
 kernel_ms_profiled = sum(dur) / len(dur) if dur else None
 

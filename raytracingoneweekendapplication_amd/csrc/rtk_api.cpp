@@ -297,6 +297,22 @@ inline float round_up(double x) {
     return double(f) < x ? std::nextafterf(f, INFINITY) : f;
 }
 
+// How far an f32 culling box is grown beyond its outward-rounded bounds.  RTK_SIGNED_SLAB: the ray carries the error of
+// its own origin term (a bracket of o/d, rtk_trace.hip begin_culling32), so a box answers only for the product b * rcp(d)
+// -- float(d) 2^-24, v_rcp_f32 one ulp, the fused multiply-add's final rounding 2^-24 of it: < 2^-22 relative -- i.e. a
+// plane displaced by < 2^-22 |b|; grown by 2^-21 of the box's largest coordinate (twice that).  Otherwise: the scene-wide
+// margin the caller computed (2^-19 x extent).
+static double box_margin(const rtk_aabb& b, double scene_margin) {
+#if RTK_SIGNED_SLAB
+    (void)scene_margin;
+    double big = 0.0;
+    for (double v : {b.xmin, b.xmax, b.ymin, b.ymax, b.zmin, b.zmax}) big = std::max(big, std::fabs(v));
+    return std::ldexp(big, -21) + 1e-300;
+#else
+    return scene_margin;
+#endif
+}
+
 // The MIXED program of rtk_device_layout.h for a sphere-only scene whose boxes carry rtk_scene_optimize's margin:
 // f32 culling boxes (rounded outward, then grown by 2^-19 of the largest coordinate in play), f64 spheres.
 // Error budget of the f32 slab test t = fma(b, inv32, -(o32 * inv32)) with inv32 = rcp(float(d)) (1 ulp), o32 =
@@ -341,9 +357,10 @@ static void build_mixed_program(const rtk_scene_desc& sc, const Program& prog, d
         rank_of_unit[unit_of_op[i]] = prog.ranks[i];
         if (kind == OP_BOX) {
             const rtk_aabb& b = sc.bvh_boxes[payload];
-            rec->f[0] = round_down(b.xmin - margin); rec->f[1] = round_up(b.xmax + margin);
-            rec->f[2] = round_down(b.ymin - margin); rec->f[3] = round_up(b.ymax + margin);
-            rec->f[4] = round_down(b.zmin - margin); rec->f[5] = round_up(b.zmax + margin);
+            const double m = box_margin(b, margin);
+            rec->f[0] = round_down(b.xmin - m); rec->f[1] = round_up(b.xmax + m);
+            rec->f[2] = round_down(b.ymin - m); rec->f[3] = round_up(b.ymax + m);
+            rec->f[4] = round_down(b.zmin - m); rec->f[5] = round_up(b.zmax + m);
             rec->aux = unit_of_op[op.aux];
         } else if (kind == OP_SPHERE || kind == OP_SPHERE_MOVING) {
             const rtk_sphere& s = sc.spheres[payload];
@@ -425,9 +442,10 @@ static void build_compact_program(const rtk_scene_desc& sc, const Program& prog,
         switch (kind) {
             case OP_BOX: {
                 const rtk_aabb& b = sc.bvh_boxes[payload];
-                head->f[0] = round_down(b.xmin - margin); head->f[1] = round_up(b.xmax + margin);
-                head->f[2] = round_down(b.ymin - margin); head->f[3] = round_up(b.ymax + margin);
-                head->f[4] = round_down(b.zmin - margin); head->f[5] = round_up(b.zmax + margin);
+                const double m = box_margin(b, margin);
+                head->f[0] = round_down(b.xmin - m); head->f[1] = round_up(b.xmax + m);
+                head->f[2] = round_down(b.ymin - m); head->f[3] = round_up(b.ymax + m);
+                head->f[4] = round_down(b.zmin - m); head->f[5] = round_up(b.zmax + m);
                 head->aux = unit_of_op[op.aux];
                 break;
             }
@@ -709,10 +727,6 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
     out.view.n_units16 = 0;
     out.view.tie_rank = nullptr;
     out.view.tie_rank_slot = nullptr;
-    out.view.box_cache16 = nullptr;
-    out.view.kind_words16 = nullptr;
-    out.view.box_rank16 = nullptr;
-    out.view.n_cached_boxes16 = out.view.n_kind_words16 = out.view.n_rank_words16 = 0;
     if (fast_order) {  // reference ranks of the primitive records, for exact ties (see SceneView::tie_rank)
         std::vector<uint32_t> rank_of_slot(slots.size(), 0u);
         bool any = false;
@@ -737,37 +751,6 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
             if ((rc = out.upload(units, &out.view.program_compact)) != RTK_OK) return rc;
             if ((rc = out.upload(ranks, &out.view.tie_rank)) != RTK_OK) return rc;
             out.view.n_units16 = int32_t(units.size());
-            // too large for LDS: the box heads alone, with the tables that find them (F_LDS_BOXES on the COMPACT program)
-            if (units.size() * sizeof(Unit16) + mats.size() * sizeof(MaterialRec<real>) > size_t(kLdsBytesPerCU)) {
-                std::vector<MixedHead> boxes;
-                std::vector<uint32_t> kind_words((units.size() + 7) / 8, 0u);
-                std::vector<uint2> rank((units.size() + 31) / 32, uint2{0u, 0u});
-                for (size_t pc = 0; pc < units.size();) {
-                    const MixedHead* head = reinterpret_cast<const MixedHead*>(&units[pc]);
-                    const uint32_t kind = head->kind_payload & 15u;
-                    kind_words[pc >> 3] |= kind << ((pc & 7) * 4);
-                    if (kind == OP_BOX) {
-                        rank[pc >> 5].x |= 1u << (pc & 31);
-                        boxes.push_back(*head);
-                    }
-                    pc += size_t(compact_units(kind));
-                }
-                uint32_t before = 0;
-                for (auto& r : rank) {
-                    r.y = before;
-                    before += uint32_t(__builtin_popcount(r.x));
-                }
-                const size_t bytes = boxes.size() * sizeof(MixedHead) + ((kind_words.size() * 4 + 7) & ~size_t(7)) + rank.size() * 8;
-                if (getenv("RTK_DEBUG")) fprintf(stderr, "[rtk] COMPACT program: %zu units (%zu B), %zu boxes, boxes + tables %zu B\n", units.size(), units.size() * 16, boxes.size(), bytes);
-                if (!boxes.empty() && bytes + 64 <= size_t(kLdsBytesPerCU)) {
-                    if ((rc = out.upload(boxes, &out.view.box_cache16)) != RTK_OK) return rc;
-                    if ((rc = out.upload(kind_words, &out.view.kind_words16)) != RTK_OK) return rc;
-                    if ((rc = out.upload(rank, &out.view.box_rank16)) != RTK_OK) return rc;
-                    out.view.n_cached_boxes16 = int32_t(boxes.size());
-                    out.view.n_kind_words16 = int32_t(kind_words.size());
-                    out.view.n_rank_words16 = int32_t(rank.size());
-                }
-            }
         }
     }
     return RTK_OK;

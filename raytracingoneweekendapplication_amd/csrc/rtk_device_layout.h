@@ -30,6 +30,13 @@
 #include <stdint.h>
 #include <hip/hip_vector_types.h>
 
+// f32 culling boxes (MIXED / COMPACT programs): 1 = the sign-selected slab test with a per-ray bracket of o/d, boxes grown by
+// 2^-21 of their OWN coordinates; 0 = the min/max form, boxes grown by 2^-19 of the largest coordinate in the scene.  Shared
+// by the kernels (rtk_trace.hip) and the program builders (rtk_api.cpp); A/B builds pass -DRTK_SIGNED_SLAB=0.
+#ifndef RTK_SIGNED_SLAB
+#define RTK_SIGNED_SLAB 1
+#endif
+
 namespace rtk {
 
 enum OpKind : uint32_t {
@@ -238,12 +245,6 @@ struct SceneView {  // device pointers, passed to the kernel by value
     const uint32_t* kind_words;
     const uint2* box_rank;
     int32_t n_cached_boxes, n_kind_words, n_rank_words;
-    // ... and the same three tables for a COMPACT program larger than LDS: its box heads (32 bytes each), kind nibbles and
-    // rank words per 16-byte unit
-    const MixedHead* box_cache16;
-    const uint32_t* kind_words16;
-    const uint2* box_rank16;
-    int32_t n_cached_boxes16, n_kind_words16, n_rank_words16;
 };
 
 struct TileMap {  // which tiles this launch renders and where the pixels go

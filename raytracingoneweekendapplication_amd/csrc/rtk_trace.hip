@@ -386,6 +386,9 @@ struct Lane {
     // F_F32_BOX kernels: the ray as the f32 culling boxes see it -- 1/d and o/d in float, the query interval rounded
     // outward.  inv and oi above are dead there.
     V3<float> inv32, oi32;
+#if RTK_SIGNED_SLAB
+    V3<float> oi32_lo;  // oi32 holds the UPPER bracket of o/d, this the lower one (see begin_culling32)
+#endif
     float tmin32, tmax32;
     real a, inv_a, tm;       // d.d (sphere.h:35, hoisted likewise) and 1/(d.d) for divide_by; ray time
     real tmin, best_t;       // current query interval: (tmin, closest so far)
@@ -435,6 +438,18 @@ RTK_DEV void begin_culling32(Lane<real>& L, V3<real> o, V3<real> d, float extent
     const V3<float> d32 = V3<float>{float(d.x), float(d.y), float(d.z)};
     L.inv32 = V3<float>{__builtin_amdgcn_rcpf(d32.x), __builtin_amdgcn_rcpf(d32.y), __builtin_amdgcn_rcpf(d32.z)};
     L.oi32 = V3<float>{float(o.x) * L.inv32.x, float(o.y) * L.inv32.y, float(o.z) * L.inv32.z};
+#if RTK_SIGNED_SLAB
+    // The origin's share of the float error travels with the RAY: o/d is bracketed, oi32_lo <= o/d <= oi32 -- the float
+    // product is off by < 2^-21.9 relative (float(o) 2^-24, v_rcp_f32 1 ulp on float(d) 2^-24, the product 2^-24), and the
+    // slab test's own final rounding adds 2^-24 of it -- so the boxes only have to carry their OWN share, 2^-21 of their own
+    // coordinates (rtk_api.cpp), not 2^-19 of the largest coordinate in the scene.
+    {
+        const float k = 4.7683716e-07f;  // 2^-21
+        const V3<float> e = V3<float>{__builtin_fabsf(L.oi32.x) * k, __builtin_fabsf(L.oi32.y) * k, __builtin_fabsf(L.oi32.z) * k};
+        L.oi32_lo = V3<float>{L.oi32.x - e.x, L.oi32.y - e.y, L.oi32.z - e.z};
+        L.oi32 = V3<float>{L.oi32.x + e.x, L.oi32.y + e.y, L.oi32.z + e.z};
+    }
+#endif
     const float big = 3.0e38f;
     const bool ok = __builtin_fabsf(L.inv32.x) < big && __builtin_fabsf(L.inv32.y) < big && __builtin_fabsf(L.inv32.z) < big &&
                     __builtin_fabsf(d32.x) < big && __builtin_fabsf(d32.y) < big && __builtin_fabsf(d32.z) < big &&
@@ -544,12 +559,42 @@ RTK_DEV bool slab_test32(const MixedHead& b, V3<float> oi, V3<float> inv, float 
     return far >= near;  // >= : a tie is let through (conservative)
 }
 // UNITS = length of a box record: 1 in the MIXED program (32-byte units), 2 in the COMPACT one (16-byte units)
+#if RTK_SIGNED_SLAB
+// The sign-selected form: which bound of an axis is the near plane depends only on the sign of that direction component,
+// known per ray -- three wave-level masks (SGPR pairs, taken once at the loop's entry: no lane changes its ray inside it)
+// pick it with six v_cndmask instead of six min/max, so near and far planes can use the two ends of the o/d bracket:
+// near = b_near/d - (o/d)_upper, far = b_far/d - (o/d)_lower.  Same instruction count as slab_test32.
+struct SignMasks {
+    unsigned long long x, y, z;  // bit l: lane l's direction component is negative
+};
+RTK_DEV float pick(float a, float b, unsigned long long mask) {  // lane-wise: mask bit set ? b : a
+    float r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+    return r;
+}
+RTK_DEV bool slab_test32_signed(const MixedHead& b, V3<float> oi_hi, V3<float> oi_lo, V3<float> inv, float tmin, float tmax, const SignMasks& m) {
+    const float nx = __builtin_fmaf(pick(b.f[0], b.f[1], m.x), inv.x, -oi_hi.x), fx = __builtin_fmaf(pick(b.f[1], b.f[0], m.x), inv.x, -oi_lo.x);
+    const float ny = __builtin_fmaf(pick(b.f[2], b.f[3], m.y), inv.y, -oi_hi.y), fy = __builtin_fmaf(pick(b.f[3], b.f[2], m.y), inv.y, -oi_lo.y);
+    const float nz = __builtin_fmaf(pick(b.f[4], b.f[5], m.z), inv.z, -oi_hi.z), fz = __builtin_fmaf(pick(b.f[5], b.f[4], m.z), inv.z, -oi_lo.z);
+    const float near = raw_max(raw_max3(nx, ny, nz), tmin);
+    const float far = raw_min(raw_min3(fx, fy, fz), tmax);
+    return far >= near;
+}
 template <uint32_t UNITS = 1, typename real, bool COUNT>
-RTK_DEV void step_box32(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cnt) {
+RTK_DEV void step_box32(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cnt, const SignMasks& m) {
+    cnt.inc(C_BOX);
+    const bool hit = slab_test32_signed(rec, L.oi32, L.oi32_lo, L.inv32, L.tmin32, L.tmax32, m);
+    L.pc = hit ? L.pc + UNITS : rec.aux;
+}
+#else
+struct SignMasks {};
+template <uint32_t UNITS = 1, typename real, bool COUNT>
+RTK_DEV void step_box32(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cnt, const SignMasks&) {
     cnt.inc(C_BOX);
     const bool hit = slab_test32(rec, L.oi32, L.inv32, L.tmin32, L.tmax32);
     L.pc = hit ? L.pc + UNITS : rec.aux;
 }
+#endif
 // A box of those programs for a ray the float test must not judge (zero / out-of-range direction component, origin
 // outside the sized bound): aabb::hit's literal form in f64 on the (outward-rounded, hence still enclosing) bounds.
 template <bool XF = false, uint32_t UNITS = 1, typename real, bool COUNT>
@@ -1046,10 +1091,14 @@ RTK_DEV uint8_t to_byte(double x) {  // Camera.txt:29-34,77-83
 //
 // Each workgroup first stages the traversal program from HBM into LDS with
 // coalesced 16-byte loads (when IN_LDS: the host checked it fits); then every
-// wave repeatedly pulls the next 8x8 tile of this rank from an atomic counter.
-// Lane l owns pixel (l & 7, l >> 3) of the tile and walks its samples in order,
-// so the per-pixel sum has the reference's summation order (Camera.txt:70-73) and
-// the image does not depend on which wave, workgroup or GPU rendered a tile.
+// wave repeatedly pulls the next work item -- an 8x8 tile of this rank x a chunk of
+// 8 samples -- from an atomic counter.  A lane owns one pixel of the item and walks
+// that chunk's samples in order; the resolve kernel adds a pixel's chunks in index
+// order.  The sum is therefore a fixed function of (scene, camera, seed, pixel) --
+// the image does not depend on which wave, workgroup or GPU rendered what -- but it
+// is NOT the reference's left-to-right sum over all samples (Camera.txt:70-73): with
+// chunked partial sums and the iterative throughput product the linear image agrees
+// with the reference to ~1e-17 (asserted < 1e-12), and only the u8 bytes are equal.
 //
 // Paths have 1..max_depth segments and rays visit 1..100+ program records, so a
 // lock-step "all lanes trace, then all lanes shade" loop leaves ~90 % of the
@@ -1182,7 +1231,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
     // ... the MIXED program of sphere-only scenes (32-byte units) or, for every other family, the COMPACT program (16-byte units)
     constexpr bool COMPACT = MIXED && (FEAT & ~uint32_t(F_F32_BOX | F_MATTE)) != kFeatLean;
     static_assert(!MIXED || sizeof(real) == 8, "F_F32_BOX: f64 kernels only");
-    static_assert(!SPLIT || !MIXED || COMPACT, "F_LDS_BOXES with f32 boxes: the COMPACT program");
+    static_assert(!SPLIT || !MIXED, "F_LDS_BOXES: slot programs only (a COMPACT program split between LDS and memory lost to the slot program: C4 175 vs 95 ms)");
     constexpr bool XF = (FEAT & F_XFORM) != 0;
     using ProgRec = std::conditional_t<COMPACT, Unit16, std::conditional_t<MIXED, MixedHead, Slot<real>>>;  // what pc counts
     using CurRec = std::conditional_t<MIXED, MixedHead, Slot<real>>;                                      // the record head a step holds in registers
@@ -1205,22 +1254,15 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
         prog = reinterpret_cast<const ProgRec*>(lds_program);
         mats = reinterpret_cast<const MaterialRec<real>*>(lds_program + size_t(n_prog16) * 16);
     }
-    using BoxCacheRec = std::conditional_t<COMPACT, MixedHead, BoxRec<real>>;  // what F_LDS_BOXES keeps per box
+    using BoxCacheRec = BoxRec<real>;  // what F_LDS_BOXES keeps per box
     [[maybe_unused]] const BoxCacheRec* lds_boxes = nullptr;
     [[maybe_unused]] const uint32_t* lds_kinds = nullptr;
     [[maybe_unused]] const uint2* lds_rank = nullptr;
     if constexpr (SPLIT) {
-        const BoxCacheRec* cache;
-        const uint32_t* kind_words;
-        const uint2* box_rank;
-        int n_boxes, n_kind_words, n_rank_words;
-        if constexpr (COMPACT) {
-            cache = sc.box_cache16; kind_words = sc.kind_words16; box_rank = sc.box_rank16;
-            n_boxes = sc.n_cached_boxes16; n_kind_words = sc.n_kind_words16; n_rank_words = sc.n_rank_words16;
-        } else {
-            cache = sc.box_cache; kind_words = sc.kind_words; box_rank = sc.box_rank;
-            n_boxes = sc.n_cached_boxes; n_kind_words = sc.n_kind_words; n_rank_words = sc.n_rank_words;
-        }
+        const BoxCacheRec* cache = sc.box_cache;
+        const uint32_t* kind_words = sc.kind_words;
+        const uint2* box_rank = sc.box_rank;
+        const int n_boxes = sc.n_cached_boxes, n_kind_words = sc.n_kind_words, n_rank_words = sc.n_rank_words;
         const size_t box_bytes = size_t(n_boxes) * sizeof(BoxCacheRec);  // a multiple of 8
         const uint2* __restrict__ src = reinterpret_cast<const uint2*>(cache);
         uint2* dst = reinterpret_cast<uint2*>(lds_program);
@@ -1258,10 +1300,8 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
     [[maybe_unused]] auto box_at = [&](uint32_t pc) -> CurRec {
         const uint2 e = lds_rank[pc >> 5];
         const uint32_t at = e.y + uint32_t(__builtin_popcount(e.x & ((1u << (pc & 31u)) - 1u)));
-        if constexpr (COMPACT) {
-            return lds_boxes[at];
-        } else if constexpr (MIXED) {
-            return CurRec{};  // (the MIXED program of sphere-only scenes always fits LDS: no boxes-in-LDS kernel)
+        if constexpr (MIXED) {
+            return CurRec{};  // (the f32-box programs are only used when they fit LDS whole: no boxes-in-LDS kernel)
         } else {
             const BoxRec<real> b = lds_boxes[at];
             Slot<real> s;
@@ -1513,6 +1553,14 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             }
             const uint32_t box_kind = L.box_kind;  // a lane with an irregular ray matches nothing here: it never steps in this loop
             int remaining;
+            [[maybe_unused]] SignMasks signs;
+#if RTK_SIGNED_SLAB
+            if constexpr (MIXED) {  // per-lane direction signs as wave masks; rays do not change inside this loop
+                signs.x = __ballot(L.inv32.x < 0.0f);
+                signs.y = __ballot(L.inv32.y < 0.0f);
+                signs.z = __ballot(L.inv32.z < 0.0f);
+            }
+#endif
 #if RTK_AB_BOX_PRIO
             __builtin_amdgcn_s_setprio(RTK_AB_BOX_PRIO);
 #endif
@@ -1522,7 +1570,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             // also keeps the loop populated for longer.
             do {
                 if (k == box_kind) {
-                    if constexpr (MIXED) step_box32<kBoxUnits>(L, cur, cnt);
+                    if constexpr (MIXED) step_box32<kBoxUnits>(L, cur, cnt, signs);
                     else step_box<false, XF, (FEAT & F_FMA_BOX) != 0>(L, cur, cnt);
                     fetch();
                     L.kind = k;
@@ -1532,7 +1580,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                     // further box steps before the loop's scalar checks (vote / sphere / exit): the checks are a
                     // dependent v_cmp -> s_bcnt1 -> s_cmp -> branch chain per step, and the kernel is latency-bound
                     if (k == box_kind) {
-                        if constexpr (MIXED) step_box32<kBoxUnits>(L, cur, cnt);
+                        if constexpr (MIXED) step_box32<kBoxUnits>(L, cur, cnt, signs);
                         else step_box<false, XF, (FEAT & F_FMA_BOX) != 0>(L, cur, cnt);
                         fetch();
                         L.kind = k;
@@ -1965,8 +2013,7 @@ static size_t lds_image_bytes(const SceneView<real>& sc, uint32_t feat) {
 
 // F_LDS_BOXES kernels: the box slots, the kind nibbles (padded to 8 bytes) and the rank table.
 template <typename real>
-static size_t split_lds_bytes(const SceneView<real>& sc, uint32_t feat) {
-    if (is_compact(feat)) return size_t(sc.n_cached_boxes16) * sizeof(MixedHead) + ((size_t(sc.n_kind_words16) * 4 + 7) & ~size_t(7)) + size_t(sc.n_rank_words16) * 8;
+static size_t split_lds_bytes(const SceneView<real>& sc, uint32_t) {
     return size_t(sc.n_cached_boxes) * sizeof(BoxRec<real>) + ((size_t(sc.n_kind_words) * 4 + 7) & ~size_t(7)) + size_t(sc.n_rank_words) * 8;
 }
 template <typename real, uint32_t FEAT, bool COUNT, bool IN_LDS>
@@ -2058,8 +2105,7 @@ static KernelChoice choose_kernel(const SceneView<real>& sc, uint32_t features, 
     }
     k.in_lds = fits;
     // a program larger than LDS whose box records are not: the boxes-in-LDS kernel (mesh and full-feature families)
-    const bool has_cache = is_compact(k.feat) ? sc.box_cache16 != nullptr : sc.box_cache != nullptr;
-    if (!fits && has_cache && (scene == kFeatMesh || scene == kFeatAll) && (diag & (1u << 21)) == 0) k.feat |= uint32_t(F_LDS_BOXES);
+    if (!fits && !(k.feat & F_F32_BOX) && sc.box_cache != nullptr && (scene == kFeatMesh || scene == kFeatAll) && (diag & (1u << 21)) == 0) k.feat |= uint32_t(F_LDS_BOXES);
     return k;
 }
 

@@ -273,9 +273,10 @@ typedef struct rtk_optimize_opts {
     int32_t has_eye;        /* != 0: order children by distance to `eye` (camera::center, Camera.txt:125) */
     int32_t max_leaf;       /* most primitives tested in a row without a box of their own (0 = 4) */
     rtk_vec3 eye;
-    double prim_cost_scale; /* scales the cost of a primitive test relative to a slab test in the SAH.  0 = automatic: 1.0,
-                             * except that a scene with triangles is re-grouped at 1.4 when the resulting COMPACT program
-                             * still fits one CU's LDS (more boxes, fewer triangle tests: C4 69.0 -> 67.0 ms) */
+    double prim_cost_scale; /* scales the cost of a primitive test relative to a slab test in the SAH.  0 = automatic: 1.0
+                             * for scenes with quads; scenes of spheres and triangles are re-grouped at 1.5 (then 1.4,
+                             * 1.2) as long as the resulting program still fits one CU's LDS (more boxes, fewer primitive
+                             * tests: C4 66.0 -> 63.5 ms) */
 } rtk_optimize_opts;
 
 typedef struct rtk_optimize_info {

@@ -660,20 +660,23 @@ static size_t compact_program_bytes(const rtk_scene_desc& d) {
     return bytes;
 }
 
-// With opts->prim_cost_scale left at 0 ("automatic"), a scene with triangles is first re-grouped with primitive tests
-// priced 1.4x dearer -- more, tighter boxes and fewer triangle tests, which is what pays once the kernels read the
-// triangles from LDS (C4: 69.0 -> 67.0 ms) -- and that hierarchy is kept only if its COMPACT program still fits one CU's
-// LDS: a program that must be split between LDS and memory loses far more than the better hierarchy gains (C4 at 1.6x:
-// 175 ms).  An explicit scale is honoured as given.
+// With opts->prim_cost_scale left at 0 ("automatic"), a scene of spheres and triangles is re-grouped with primitive tests
+// priced 1.5x dearer -- more, tighter boxes and fewer primitive tests, which is what pays once the kernels read everything
+// from LDS (C4: 66.0 -> 63.5 ms, C2: 21.31 -> 21.23) -- as long as its COMPACT program still fits one CU's LDS: a program
+// that has to leave LDS loses far more than the better hierarchy gains (C4 at 1.6x: 175 ms), so the scale steps down
+// (1.4, 1.2, 1.0) until it fits.  Scenes with quads keep 1.0 (the Cornell box is flat between 1.0 and 1.5 and worse in
+// between).  An explicit scale is honoured as given.
 int rtk_scene_optimize(const rtk_scene_desc* scene, const rtk_optimize_opts* opts_in, rtk_scene_desc** out_scene, rtk_optimize_info* info) {
     if (!scene || !out_scene) return RTK_ERR_INVALID;
     rtk_optimize_opts o;
     std::memset(&o, 0, sizeof o);
     if (opts_in) o = *opts_in;
-    if (!(o.prim_cost_scale > 0) && scene->n_triangles > 0) {
-        o.prim_cost_scale = 1.4;
-        rtk_optimize_info local;
-        if (optimize_once(scene, &o, out_scene, &local) == RTK_OK) {
+    if (!(o.prim_cost_scale > 0) && scene->n_quads == 0) {
+        for (double scale : {1.5, 1.4, 1.2}) {
+            o.prim_cost_scale = scale;
+            rtk_optimize_info local;
+            const int rc = optimize_once(scene, &o, out_scene, &local);
+            if (rc != RTK_OK) return rc;
             if (compact_program_bytes(**out_scene) + 2048 <= size_t(160) * 1024) {
                 if (info) *info = local;
                 return RTK_OK;

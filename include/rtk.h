@@ -262,11 +262,14 @@ int rtk_scene_validate(const rtk_scene_desc* scene, int32_t* n_program_ops);
  * RTK_NODE_BVH / RTK_NODE_LIST nodes; upload that instead of `scene` to render
  * with fewer aabb::hit calls per ray.  The reference's own order (bvh.h:13-45
  * median split, bvh.h:64-72 left then right) stays the default everywhere else.
- * The closest hit of every ray is preserved, so for scenes without a
- * constant_medium and without triangles the image is bit-identical (info->exact
- * = 1); a medium draws a random number inside hit() (constant_medium.h:40), so
- * with media the RNG order changes and parity is statistical; with triangles see
- * rtk_optimize_info.has_triangles.  The work counters differ by design.  *out_scene borrows every table of `scene` except nodes,
+ * The closest hit of every ray is preserved and exact ties go to the primitive
+ * the reference would have kept (rtk_node.c ranks), so the image is bit-identical
+ * (info->exact = 1).  A constant_medium draws a random number inside hit()
+ * (constant_medium.h:40), and whether hit() runs depends on what the reference
+ * visited before it: media, and the groups above them, therefore keep the
+ * reference's structure and only what holds no medium is re-grouped (see
+ * opts->free_media_order).  With triangles see rtk_optimize_info.has_triangles.
+ * The work counters differ by design.  *out_scene borrows every table of `scene` except nodes,
  * list_children and bvh_boxes: keep `scene` alive while it is in use, release it
  * with rtk_scene_optimized_free. */
 typedef struct rtk_optimize_opts {
@@ -277,14 +280,21 @@ typedef struct rtk_optimize_opts {
                              * for scenes with quads; scenes of spheres and triangles are re-grouped at 1.5 (then 1.4,
                              * 1.2) as long as the resulting program still fits one CU's LDS (more boxes, fewer primitive
                              * tests: C4 66.0 -> 63.5 ms) */
+    int32_t free_media_order; /* 0 (default): a constant_medium, and every bvh_node / hittable_list above one, keeps the
+                               * reference's structure and order, so the medium meets the same interval and draws the same
+                               * random numbers as in the reference: the image stays bit-identical (info->exact = 1).
+                               * != 0: media are re-grouped like any other object -- somewhat fewer box tests, but the
+                               * order of the draws inside constant_medium::hit changes and parity becomes statistical */
+    int32_t _pad;
 } rtk_optimize_opts;
 
 typedef struct rtk_optimize_info {
-    int32_t exact;              /* 1: images are bit-identical to the reference order (no medium, no triangle) */
-    int32_t has_media;          /* a constant_medium draws inside hit(): the RNG order changes, parity is statistical */
+    int32_t exact;              /* 1: images are bit-identical to the reference order */
+    int32_t has_media;          /* a constant_medium draws inside hit(): exact only while opts->free_media_order == 0 */
     int32_t has_triangles;      /* triangle::hit's float determinant (triangle.h:72,77): identical except where the
                                  * reference's own boxes cull a hit that triangle::hit accepts (order-dependent) */
-    int32_t n_bvh_nodes_in, n_bvh_nodes_out, _pad;
+    int32_t n_bvh_nodes_in, n_bvh_nodes_out;
+    int32_t n_kept_nodes;       /* bvh_node / hittable_list nodes kept as the reference has them because a medium lies below */
     double expected_cost;       /* SAH estimate, in slab tests, of one closest-hit query */
     double box_margin;          /* every new box is grown by this much (2^-40 of the scene extent) */
 } rtk_optimize_info;

@@ -73,13 +73,24 @@ class RenderOpts(C.Structure):
 class OptimizeOpts(C.Structure):
     """rtk_optimize_opts (include/rtk.h)."""
 
-    _fields_ = [("has_eye", C.c_int32), ("max_leaf", C.c_int32), ("eye", Vec3), ("prim_cost_scale", C.c_double)]
+    _fields_ = [("has_eye", C.c_int32), ("max_leaf", C.c_int32), ("eye", Vec3), ("prim_cost_scale", C.c_double),
+                ("free_media_order", C.c_int32), ("_pad", C.c_int32)]
 
 
 class OptimizeInfo(C.Structure):
     _fields_ = [("exact", C.c_int32), ("has_media", C.c_int32), ("has_triangles", C.c_int32),
-                ("n_bvh_nodes_in", C.c_int32), ("n_bvh_nodes_out", C.c_int32), ("_pad", C.c_int32),
+                ("n_bvh_nodes_in", C.c_int32), ("n_bvh_nodes_out", C.c_int32), ("n_kept_nodes", C.c_int32),
                 ("expected_cost", C.c_double), ("box_margin", C.c_double)]
+
+
+def _optimize_opts(eye, max_leaf, prim_cost_scale, free_media_order) -> OptimizeOpts:
+    return OptimizeOpts(1 if eye is not None else 0, max_leaf, eye if eye is not None else Vec3(0, 0, 0), prim_cost_scale, 1 if free_media_order else 0, 0)
+
+
+def _optimize_info(info: OptimizeInfo) -> dict:
+    return {"exact": bool(info.exact), "has_media": bool(info.has_media), "has_triangles": bool(info.has_triangles),
+            "n_bvh_nodes_in": info.n_bvh_nodes_in, "n_bvh_nodes_out": info.n_bvh_nodes_out, "n_kept_nodes": info.n_kept_nodes,
+            "expected_cost": info.expected_cost, "box_margin": info.box_margin}
 
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_int64, C.c_int64, C.c_void_p)  # rtk_progress_fn
@@ -238,9 +249,9 @@ class Scene:
             raise ValueError(f"cannot derive a {width}x{height} camera for {self.name} (rc={rc})")
         return cam
 
-    def fast_order(self, eye: Optional[Vec3] = None, max_leaf: int = 0, prim_cost_scale: float = 0.0) -> "FastOrderScene":
+    def fast_order(self, eye: Optional[Vec3] = None, max_leaf: int = 0, prim_cost_scale: float = 0.0, free_media_order: bool = False) -> "FastOrderScene":
         """The same primitives re-grouped by rtk_scene_optimize (host-only pass of librtk_hip.so)."""
-        return FastOrderScene(self, eye, max_leaf, prim_cost_scale)
+        return FastOrderScene(self, eye, max_leaf, prim_cost_scale, free_media_order)
 
     def close(self) -> None:
         if self._h:
@@ -257,21 +268,21 @@ class Scene:
 class FastOrderScene:
     """rtk_scene_optimize output: a description that borrows the tables of `base` (kept alive here).
 
-    ``exact`` says whether rendering it gives bit-identical images to the reference order (no constant_medium).
+    ``exact`` says whether rendering it gives bit-identical images to the reference order (always, unless media were
+    re-grouped too: ``free_media_order``).
     """
 
-    def __init__(self, base: Scene, eye: Optional[Vec3] = None, max_leaf: int = 0, prim_cost_scale: float = 0.0):
+    def __init__(self, base: Scene, eye: Optional[Vec3] = None, max_leaf: int = 0, prim_cost_scale: float = 0.0, free_media_order: bool = False):
         self.base = base
         self.name = base.name + "+fast_order"
-        opts = OptimizeOpts(1 if eye is not None else 0, max_leaf, eye if eye is not None else Vec3(0, 0, 0), prim_cost_scale)
+        self.opts = opts = _optimize_opts(eye, max_leaf, prim_cost_scale, free_media_order)
         out, info = C.c_void_p(), OptimizeInfo()
         rc = hip_lib().rtk_scene_optimize(base.desc_ptr, C.byref(opts), C.byref(out), C.byref(info))
         if rc != 0 or not out.value:
             raise RtkError(rc, "rtk_scene_optimize failed")
         self._h = out.value
         self.exact = bool(info.exact)
-        self.info = {"exact": bool(info.exact), "has_media": bool(info.has_media), "has_triangles": bool(info.has_triangles), "n_bvh_nodes_in": info.n_bvh_nodes_in, "n_bvh_nodes_out": info.n_bvh_nodes_out,
-                     "expected_cost": info.expected_cost, "box_margin": info.box_margin}
+        self.info = _optimize_info(info)
 
     @property
     def desc_ptr(self) -> int:
@@ -353,20 +364,18 @@ class Renderer:
     def upload(self, scene) -> None:
         self._check(self._lib.rtk_scene_upload(self._ctx, scene.desc_ptr))
 
-    def upload_fast(self, scene, eye: Optional[Vec3] = None, max_leaf: int = 0, prim_cost_scale: float = 0.0) -> dict:
-        """rtk_scene_upload_fast: optimise the visiting order and upload, with the fused slab test enabled.
+    def upload_fast(self, scene, eye: Optional[Vec3] = None, max_leaf: int = 0, prim_cost_scale: float = 0.0, free_media_order: bool = False) -> dict:
+        """rtk_scene_upload_fast: optimise the visiting order and upload, with the fast-order kernels.
         Returns the rtk_optimize_info fields."""
-        opts = OptimizeOpts(1 if eye is not None else 0, max_leaf, eye if eye is not None else Vec3(0, 0, 0), prim_cost_scale)
+        opts = _optimize_opts(eye, max_leaf, prim_cost_scale, free_media_order)
         info = OptimizeInfo()
         self._check(self._lib.rtk_scene_upload_fast(self._ctx, scene.desc_ptr, C.byref(opts), C.byref(info)))
-        return {"exact": bool(info.exact), "has_media": bool(info.has_media), "has_triangles": bool(info.has_triangles),
-                "n_bvh_nodes_in": info.n_bvh_nodes_in, "n_bvh_nodes_out": info.n_bvh_nodes_out,
-                "expected_cost": info.expected_cost, "box_margin": info.box_margin}
+        return _optimize_info(info)
 
-    def upload_optimized(self, scene, eye: Optional[Vec3] = None) -> None:
+    def upload_optimized(self, scene, eye: Optional[Vec3] = None, free_media_order: bool = False) -> None:
         """rtk_scene_upload_optimized: a description that already IS a re-grouped hierarchy (rtk_scene_optimize output, or a
         hand-built one whose primitive nodes carry reference ranks in rtk_node.c), with the fast-order kernels."""
-        opts = OptimizeOpts(1 if eye is not None else 0, 0, eye if eye is not None else Vec3(0, 0, 0), 0.0)
+        opts = _optimize_opts(eye, 0, 0.0, free_media_order)
         self._check(self._lib.rtk_scene_upload_optimized(self._ctx, scene.desc_ptr, C.byref(opts)))
 
     def scene_info(self) -> dict:
@@ -454,10 +463,10 @@ class MultiRenderer:
         self._check(self._lib.rtk_multi_scene_upload(self._m, scene.desc_ptr))
 
     def upload_fast(self, scene, eye: Optional[Vec3] = None) -> dict:
-        opts = OptimizeOpts(1 if eye is not None else 0, 0, eye if eye is not None else Vec3(0, 0, 0), 0.0)
+        opts = _optimize_opts(eye, 0, 0.0, False)
         info = OptimizeInfo()
         self._check(self._lib.rtk_multi_scene_upload_fast(self._m, scene.desc_ptr, C.byref(opts), C.byref(info)))
-        return {"exact": bool(info.exact), "has_media": bool(info.has_media), "has_triangles": bool(info.has_triangles)}
+        return _optimize_info(info)
 
     def kernel_name(self, real_mode: int = RTK_REAL_F64, variant: int = 0) -> str:
         return self._lib.rtk_kernel_name(self._lib.rtk_multi_ctx(self._m, 0), real_mode, variant).decode()

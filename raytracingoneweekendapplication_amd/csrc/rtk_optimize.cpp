@@ -14,12 +14,12 @@
 // RTK_NODE_BVH / RTK_NODE_LIST nodes over the same primitive tables, so the same
 // linear traversal program, the same kernels and the same oracle run on it.
 //
-// What is preserved: the closest hit of every ray, hence -- for scenes without a
-// constant_medium -- every pixel bit for bit (the RNG stream of a sample does not
-// depend on the visiting order unless a medium draws inside hit(),
-// constant_medium.h:40).  What changes: the work counters (fewer box tests), and
-// with media the order of those draws (parity becomes statistical; the optimiser
-// reports it through rtk_optimize_info.exact).  Triangles: triangle::hit scales
+// What is preserved: the closest hit of every ray, hence every pixel bit for bit
+// (the RNG stream of a sample does not depend on the visiting order unless a
+// medium draws inside hit(), constant_medium.h:40 -- and media keep their place in
+// the reference's order, see keep_group; only with opts.free_media_order are they
+// re-grouped too, parity then is statistical and rtk_optimize_info.exact says so).
+// What changes: the work counters (fewer box tests).  Triangles: triangle::hit scales
 // its hit distance by a float reciprocal of a float determinant (triangle.h:72,77),
 // so an accepted hit can lie ~1e-7 of the travelled distance outside the triangle's
 // exact box; whether the reference's own boxes let such a hit through depends on
@@ -112,6 +112,9 @@ struct Optimizer {
     std::vector<char> on_stack;
     std::vector<char> memo_media;    // the subtree of that input node contains a constant_medium
     std::vector<int32_t> ref_rank;   // input primitive node -> 1 + rank of its first visit in the reference order (0: never visited)
+    std::vector<char> holds_medium;  // input node -> 1: a constant_medium is reachable from it, 0: none (scan_media)
+    bool keep_media_order = true;    // media and every group above one keep the reference's structure (see keep_group)
+    int32_t n_kept = 0;
     bool failed = false;
     bool has_media = false;
     double margin = 0.0, tri_margin = 0.0;
@@ -134,6 +137,10 @@ struct Optimizer {
         }
     }
 
+    int32_t fail_node() {
+        failed = true;
+        return -1;
+    }
     int32_t push_node(int32_t kind, int32_t a, int32_t b, int32_t c) {
         out.nodes.push_back(rtk_node{kind, a, b, c});
         return int32_t(out.nodes.size()) - 1;
@@ -245,6 +252,12 @@ struct Optimizer {
                 break;
             case RTK_NODE_LIST:
             case RTK_NODE_BVH: {
+                if (keep_media_order && holds_medium[size_t(node)]) {
+                    o = keep_group(node, box, cost, depth);
+                    memo_media[node] = 1;
+                    has_media = true;
+                    break;
+                }
                 const bool media_before = has_media;
                 has_media = false;
                 o = build_group(node, box, cost, depth);
@@ -473,6 +486,123 @@ struct Optimizer {
         std::vector<Item> items;
         std::unordered_set<int32_t> present;
         if (!gather(node, items, present, depth)) return -1;
+        return build_items(items, box, cost);
+    }
+
+    // A group that holds a constant_medium, directly or further down, keeps the reference's own shape.  Whether
+    // constant_medium::hit runs for a ray -- and draws its random number (constant_medium.h:40) -- is decided by the slab
+    // tests of the bvh_nodes above it against the interval as it stands when the reference gets there (bvh.h:64-69), i.e.
+    // by everything the reference visited BEFORE.  So such a bvh_node stays a bvh_node with its own box, children in the
+    // reference's order, and such a hittable_list stays a list in order; what hangs off them without a medium inside is
+    // re-grouped freely (its closest hit within a given interval does not depend on the visiting order), and neighbouring
+    // medium-free children of a kept list are re-grouped together.  The medium then meets the same interval as in the
+    // reference, draws the same numbers, and the image stays bit-identical.
+    int32_t keep_group(int32_t node, Box& box, double& cost, int depth) {
+        const rtk_node n = in.nodes[node];
+        n_kept++;
+        if (n.kind == RTK_NODE_BVH) {
+            n_bvh_in++;
+            if (n.c < 0 || n.c >= in.n_bvh_boxes || !in.bvh_boxes) return fail_node();
+            Box ba, bb;
+            double ca = 0, cb = 0;
+            const int32_t a = convert(n.a, ba, ca, depth + 1);
+            if (a < 0) return -1;
+            const int32_t b = convert(n.b, bb, cb, depth + 1);  // a span of one lists the object twice (bvh.h:30-32): memoised, visited twice as in the reference
+            if (b < 0) return -1;
+            const rtk_aabb own = in.bvh_boxes[n.c];  // verbatim: its slab test decides what the medium below sees
+            out.boxes.push_back(own);
+            box = Box{{own.xmin, own.ymin, own.zmin}, {own.xmax, own.ymax, own.zmax}};
+            cost = kBoxCost + ca + cb;
+            return push_node(RTK_NODE_BVH, a, b, int32_t(out.boxes.size()) - 1);
+        }
+        if (n.a < 0 || n.b < 0 || int64_t(n.a) + n.b > in.n_list_children) return fail_node();
+        std::vector<int32_t> kept;
+        std::vector<Item> run;
+        std::unordered_set<int32_t> present;
+        box = Box::empty();
+        cost = 0;
+        auto close_run = [&]() {
+            if (run.empty()) return true;
+            Box rb;
+            double rc = 0;
+            const int32_t g = build_items(run, rb, rc);
+            if (g < 0) return false;
+            kept.push_back(g);
+            box.grow(rb);
+            cost += rc;
+            run.clear();
+            present.clear();
+            return true;
+        };
+        for (int32_t k = 0; k < n.b; k++) {
+            const int32_t child = in.list_children[n.a + k];
+            if (child < 0 || child >= in.n_nodes) return fail_node();
+            if (!holds_medium[size_t(child)]) {
+                if (!gather(child, run, present, depth + 1)) return -1;
+                continue;
+            }
+            if (!close_run()) return -1;
+            Box cb;
+            double cc = 0;
+            const int32_t o = convert(child, cb, cc, depth + 1);
+            if (o < 0) return -1;
+            kept.push_back(o);
+            box.grow(cb);
+            cost += cc;
+        }
+        if (!close_run()) return -1;
+        const int32_t first = int32_t(out.children.size());
+        out.children.insert(out.children.end(), kept.begin(), kept.end());
+        return push_node(RTK_NODE_LIST, first, int32_t(kept.size()), 0);
+    }
+
+    // Is a constant_medium reachable from each node?  (Iterative post-order; a cycle fails the pass.)
+    bool scan_media(int32_t root) {
+        holds_medium.assign(size_t(in.n_nodes), 0);
+        std::vector<char> state(size_t(in.n_nodes), 0);  // 0 new, 1 open, 2 done
+        std::vector<std::pair<int32_t, int32_t>> stack{{root, 0}};  // node, next child
+        auto child_of = [&](const rtk_node& n, int32_t k) -> int32_t {  // -1: no such child, -2: malformed
+            switch (n.kind) {
+                case RTK_NODE_LIST:
+                    if (n.a < 0 || n.b < 0 || int64_t(n.a) + n.b > in.n_list_children) return -2;
+                    return k < n.b ? in.list_children[n.a + k] : -1;
+                case RTK_NODE_BVH: return k == 0 ? n.a : (k == 1 ? n.b : -1);
+                case RTK_NODE_TRANSLATE: case RTK_NODE_ROTATE_Y: case RTK_NODE_MEDIUM: return k == 0 ? n.b : -1;
+                default: return -1;
+            }
+        };
+        while (!stack.empty()) {
+            auto& [node, next] = stack.back();
+            if (node < 0 || node >= in.n_nodes || stack.size() > 4100) return false;
+            const rtk_node& n = in.nodes[node];
+            if (next == 0) {
+                if (state[size_t(node)] == 2) { stack.pop_back(); continue; }
+                if (state[size_t(node)] == 1) return false;
+                state[size_t(node)] = 1;
+                if (n.kind == RTK_NODE_MEDIUM) holds_medium[size_t(node)] = 1;
+            }
+            const int32_t c = child_of(n, next);
+            if (c == -2) return false;
+            if (c == -1) {
+                state[size_t(node)] = 2;
+                const int32_t done = node;
+                stack.pop_back();
+                if (!stack.empty() && holds_medium[size_t(done)]) holds_medium[size_t(stack.back().first)] = 1;
+                continue;
+            }
+            next++;
+            if (c < 0 || c >= in.n_nodes) return false;
+            if (state[size_t(c)] == 2) {
+                if (holds_medium[size_t(c)]) holds_medium[size_t(node)] = 1;
+                continue;
+            }
+            stack.push_back({c, 0});
+        }
+        return true;
+    }
+
+    // The cheaper of a plain list and a SAH hierarchy over `items` (>= 0 of them), as one output node.
+    int32_t build_items(std::vector<Item>& items, Box& box, double& cost) {
         if (items.empty()) {  // an empty list hits nothing (hittable_list.h:22-35)
             box = Box::empty();
             cost = 0;
@@ -566,6 +696,11 @@ static int optimize_once(const rtk_scene_desc* scene, const rtk_optimize_opts* o
     Holder* h = new (std::nothrow) Holder;
     if (!h) return RTK_ERR_INVALID;
     Optimizer op(*scene, opts, *h);
+    op.keep_media_order = opts.free_media_order == 0;
+    if (!op.scan_media(scene->root)) {
+        delete h;
+        return RTK_ERR_INVALID;
+    }
     op.compute_ranks(scene->root);
     op.compute_margin();
     Box box;
@@ -584,7 +719,8 @@ static int optimize_once(const rtk_scene_desc* scene, const rtk_optimize_opts* o
     // The root box holds the whole scene.  Every secondary ray starts on a surface, i.e. inside it, and so does every
     // primary ray when the eye lies inside it: a slab test from the inside cannot fail (the interval starts at 0.001,
     // Camera.txt:211), so the root's test is dropped -- its two children are visited unconditionally, in order.
-    if (h->nodes[size_t(root)].kind == RTK_NODE_BVH && opts.has_eye) {
+    const bool root_kept = op.keep_media_order && op.holds_medium[size_t(scene->root)];  // then its test is the reference's own: it stays
+    if (h->nodes[size_t(root)].kind == RTK_NODE_BVH && opts.has_eye && !root_kept) {
         const rtk_node rn = h->nodes[size_t(root)];
         const rtk_aabb& rb = h->boxes[size_t(rn.c)];
         const bool inside = opts.eye.x > rb.xmin && opts.eye.x < rb.xmax && opts.eye.y > rb.ymin && opts.eye.y < rb.ymax && opts.eye.z > rb.zmin &&
@@ -605,10 +741,12 @@ static int optimize_once(const rtk_scene_desc* scene, const rtk_optimize_opts* o
     h->desc.n_bvh_boxes = int32_t(h->boxes.size());
     h->desc.bvh_boxes = h->boxes.data();
     if (info) {
-        // Closest hits are preserved and exact ties are resolved by the reference's ranks (rtk_node.c), so without a medium
-        // the image is the reference order's bit for bit; has_triangles flags the one caveat left (see rtk.h)
-        info->exact = op.has_media ? 0 : 1;
+        // Closest hits are preserved, exact ties are resolved by the reference's ranks (rtk_node.c) and a medium meets the
+        // interval it meets in the reference (keep_group), so the image is the reference order's bit for bit unless the
+        // caller asked for the free order of media; has_triangles flags the one caveat left (see rtk.h)
+        info->exact = (op.has_media && !op.keep_media_order) ? 0 : 1;
         info->has_media = op.has_media ? 1 : 0;
+        info->n_kept_nodes = op.n_kept;
         info->has_triangles = op.has_triangles ? 1 : 0;
         info->n_bvh_nodes_in = int32_t(op.n_bvh_in);
         info->n_bvh_nodes_out = int32_t(h->boxes.size());
@@ -660,6 +798,44 @@ static size_t compact_program_bytes(const rtk_scene_desc& d) {
     return bytes;
 }
 
+// Slots (64 B in f64) and box records of the slot program the upload compiles from `d` -- the same walk as above.  The f64
+// kernels keep a slot program whole in LDS when it fits, otherwise its box records (56 B each) plus a nibble per slot and
+// a rank word per 32 slots (rtk_api.cpp, F_LDS_BOXES).
+static void slot_program_counts(const rtk_scene_desc& d, size_t& n_slots, size_t& n_boxes) {
+    n_slots = 1;
+    n_boxes = 0;
+    std::vector<std::pair<int32_t, int>> stack{{d.root, 0}};
+    size_t guard = 0;
+    while (!stack.empty() && guard++ < (size_t(1) << 24) && n_slots < (size_t(1) << 26)) {
+        const auto [node, depth] = stack.back();
+        stack.pop_back();
+        if (node < 0 || node >= d.n_nodes || depth > 4096) continue;
+        const rtk_node& n = d.nodes[node];
+        switch (n.kind) {
+            case RTK_NODE_SPHERE: {
+                const bool moving = n.a >= 0 && n.a < d.n_spheres && (d.spheres[n.a].center_dir.x != 0 || d.spheres[n.a].center_dir.y != 0 || d.spheres[n.a].center_dir.z != 0);
+                n_slots += moving ? 2 : 1;
+                break;
+            }
+            case RTK_NODE_QUAD: n_slots += 3; break;
+            case RTK_NODE_TRIANGLE: n_slots += 2; break;
+            case RTK_NODE_LIST:
+                if (n.a >= 0 && n.b >= 0 && int64_t(n.a) + n.b <= d.n_list_children)
+                    for (int32_t k = 0; k < n.b; k++) stack.push_back({d.list_children[n.a + k], depth + 1});
+                break;
+            case RTK_NODE_BVH: n_slots++; n_boxes++; stack.push_back({n.a, depth + 1}); stack.push_back({n.b, depth + 1}); break;
+            case RTK_NODE_TRANSLATE: case RTK_NODE_ROTATE_Y: n_slots += 2; stack.push_back({n.b, depth + 1}); break;
+            case RTK_NODE_MEDIUM: {
+                const bool sphere_bound = n.b >= 0 && n.b < d.n_nodes && d.nodes[n.b].kind == RTK_NODE_SPHERE;
+                if (sphere_bound) n_slots++;
+                else { n_slots += 3; stack.push_back({n.b, depth + 1}); stack.push_back({n.b, depth + 1}); }
+                break;
+            }
+            default: break;
+        }
+    }
+}
+
 // With opts->prim_cost_scale left at 0 ("automatic"), a scene of spheres and triangles is re-grouped with primitive tests
 // priced 1.5x dearer -- more, tighter boxes and fewer primitive tests, which is what pays once the kernels read everything
 // from LDS (C4: 66.0 -> 63.5 ms, C2: 21.31 -> 21.23) -- as long as its COMPACT program still fits one CU's LDS: a program
@@ -685,6 +861,28 @@ int rtk_scene_optimize(const rtk_scene_desc* scene, const rtk_optimize_opts* opt
             *out_scene = nullptr;
         }
         o.prim_cost_scale = 0.0;
+    }
+    // A scene whose media keep their place renders from the slot program (exact boxes throughout, rtk_api.cpp).  When
+    // that program is too large for LDS, what matters is that at least its box records stay there: primitive tests
+    // are priced down step by step (fewer, larger leaves: fewer boxes) until the box table fits.
+    if (!(o.prim_cost_scale > 0) && o.free_media_order == 0) {
+        for (double scale : {1.0, 0.85, 0.7, 0.55, 0.4}) {
+            o.prim_cost_scale = scale;
+            rtk_optimize_info local;
+            const int rc = optimize_once(scene, &o, out_scene, &local);
+            if (rc != RTK_OK) return rc;
+            size_t n_slots = 0, n_boxes = 0;
+            if (local.has_media) slot_program_counts(**out_scene, n_slots, n_boxes);
+            const size_t budget = size_t(160) * 1024 - 4096;  // the kernel's own LDS words and a small material table
+            const size_t whole = n_slots * 64 + size_t(scene->n_materials) * 48;
+            const size_t boxes_only = n_boxes * 56 + n_slots / 2 + n_slots / 4 + 64;
+            if (!local.has_media || whole <= budget || boxes_only <= budget || scale == 0.4) {
+                if (info) *info = local;
+                return RTK_OK;
+            }
+            rtk_scene_optimized_free(*out_scene);
+            *out_scene = nullptr;
+        }
     }
     return optimize_once(scene, &o, out_scene, info);
 }

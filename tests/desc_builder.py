@@ -65,6 +65,10 @@ MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC, MAT
 TEX_SOLID = 1
 
 
+def _union(boxes):
+    return tuple((min if k % 2 == 0 else max)(b[k] for b in boxes) for k in range(6))
+
+
 def _cross(a, b):
     return (a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0])
 
@@ -80,6 +84,8 @@ class DescBuilder:
         self.nodes, self.children, self.spheres, self.quads, self.translates, self.rotates, self.media = [], [], [], [], [], [], []
         self.triangles = []
         self.materials, self.textures = [], []
+        self.boxes = []       # rtk_aabb of the bvh nodes
+        self.box_of = {}      # node -> (xmin, xmax, ymin, ymax, zmin, zmax) where the builder knows it (spheres and what is made of them)
 
     def _node(self, kind, a=0, b=0, c=0):
         self.nodes.append(Node(kind, a, b, c))
@@ -107,7 +113,11 @@ class DescBuilder:
 
     def sphere(self, centre, radius, material, motion=(0.0, 0.0, 0.0)):
         self.spheres.append(Sphere(Vec3(*centre), Vec3(*motion), max(0.0, radius), material, 0))
-        return self._node(NODE_SPHERE, len(self.spheres) - 1)
+        node = self._node(NODE_SPHERE, len(self.spheres) - 1)
+        r = max(0.0, radius)
+        ends = [centre, tuple(centre[k] + motion[k] for k in range(3))]                     # sphere.h:17,24-26
+        self.box_of[node] = tuple(f(e[k] + sgn * r for e in ends) for k in range(3) for f, sgn in ((min, -1), (max, 1)))
+        return node
 
     def quad(self, Q, u, v, material):
         n = _cross(u, v)                                   # quad.h:12-19
@@ -136,7 +146,42 @@ class DescBuilder:
     def list(self, members):
         first = len(self.children)
         self.children.extend(members)
-        return self._node(NODE_LIST, first, len(members))
+        node = self._node(NODE_LIST, first, len(members))
+        if all(m in self.box_of for m in members) and members:
+            self.box_of[node] = _union([self.box_of[m] for m in members])
+        return node
+
+    def isotropic(self, rgb):
+        self.materials.append(Material(MAT_ISOTROPIC, self.solid(rgb), Vec3(0, 0, 0), 0.0))
+        return len(self.materials) - 1
+
+    def medium(self, boundary, density, rgb):
+        """constant_medium(boundary, density, albedo) (constant_medium.h:12-17): neg_inv_density = -1 / density, isotropic phase."""
+        self.media.append(Medium(-1.0 / density, self.isotropic(rgb), 0))
+        node = self._node(NODE_MEDIUM, len(self.media) - 1, boundary)
+        if boundary in self.box_of:
+            self.box_of[node] = self.box_of[boundary]          # constant_medium.h:55
+        return node
+
+    def bvh(self, members, rnd):
+        """bvh_node(list) over nodes with known boxes (spheres, media bounded by them, lists and bvh nodes of those): a random
+        axis per node, sorted by box minimum, split at the middle; a span of one stores the object twice (bvh.h:13-45 in
+        the book's form -- the test only needs A valid hierarchy the optimiser has to respect, boxes bounding their content)."""
+        members = list(members)
+        axis = rnd.randrange(3)
+        members.sort(key=lambda m: self.box_of[m][2 * axis])
+        if len(members) == 1:
+            left = right = members[0]
+        elif len(members) == 2:
+            left, right = members
+        else:
+            mid = len(members) // 2
+            left, right = self.bvh(members[:mid], rnd), self.bvh(members[mid:], rnd)
+        box = _union([self.box_of[left], self.box_of[right]])
+        self.boxes.append(Aabb(*box))
+        node = self._node(NODE_BVH, left, right, len(self.boxes) - 1)
+        self.box_of[node] = box
+        return node
 
     def translate(self, child, offset):
         self.translates.append(Translate(Vec3(*offset)))
@@ -158,12 +203,13 @@ class BuiltDesc:
             return a
         self._keep = dict(nodes=arr(Node, b.nodes), children=(C.c_int32 * max(1, len(b.children)))(*b.children), spheres=arr(Sphere, b.spheres),
                           quads=arr(Quad, b.quads), translates=arr(Translate, b.translates), rotates=arr(RotateY, b.rotates), media=arr(Medium, b.media),
-                          materials=arr(Material, b.materials), textures=arr(Texture, b.textures), tris=arr(Triangle, b.triangles), boxes=arr(Aabb, []))
+                          materials=arr(Material, b.materials), textures=arr(Texture, b.textures), tris=arr(Triangle, b.triangles), boxes=arr(Aabb, b.boxes))
         k = self._keep
         d = SceneDesc()
         d.abi_version, d.root = 1, root
         d.n_nodes, d.n_list_children, d.n_spheres, d.n_quads = len(b.nodes), len(b.children), len(b.spheres), len(b.quads)
         d.n_triangles = len(b.triangles)
+        d.n_bvh_boxes = len(b.boxes)
         d.n_translates, d.n_rotates, d.n_media, d.n_materials, d.n_textures = len(b.translates), len(b.rotates), len(b.media), len(b.materials), len(b.textures)
         d.nodes, d.list_children, d.spheres, d.quads = k["nodes"], k["children"], k["spheres"], k["quads"]
         d.triangles, d.bvh_boxes, d.translates, d.rotates = k["tris"], k["boxes"], k["translates"], k["rotates"]

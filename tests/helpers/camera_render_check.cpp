@@ -69,6 +69,15 @@ int main() {
         const bool auto_used_fast = cam.used_fast_order, exact = cam.fast_order_exact;
         cam.order = camera::fast_order;
         int rc2 = cam.render_to(world, lights, &fast, nullptr);
+        // media re-grouped too: the forced fast order is then another image of the same estimator, and auto_order declines
+        std::vector<double> free_fast, free_auto;
+        cam.free_media_order = true;
+        int rc6 = cam.render_to(world, lights, &free_fast, nullptr);
+        cam.order = camera::auto_order;
+        int rc7 = cam.render_to(world, lights, &free_auto, nullptr);
+        const bool free_auto_used_fast = cam.used_fast_order, free_exact = cam.fast_order_exact;
+        cam.free_media_order = false;
+        ok = ok && rc6 == 0 && rc7 == 0;
         // camera::devices: render() owns the split over several GPUs (here the same GPU listed twice and three times:
         // two / three ranks, tile buffers, one gather, un-permute) -- the image must be the very same doubles and bytes
         std::vector<double> two, three;
@@ -93,15 +102,20 @@ int main() {
         ok = ok && rc3 == 0 && rc4 == 0 && rc5 == 0;
         const bool same_auto = ref.size() == aut.size() && std::memcmp(ref.data(), aut.data(), ref.size() * sizeof(double)) == 0;
         const bool same_fast = ref.size() == fast.size() && std::memcmp(ref.data(), fast.data(), ref.size() * sizeof(double)) == 0;
-        double mean_ref = 0, mean_fast = 0;
+        const bool same_free_fast = ref.size() == free_fast.size() && std::memcmp(ref.data(), free_fast.data(), ref.size() * sizeof(double)) == 0;
+        const bool same_free_auto = ref.size() == free_auto.size() && std::memcmp(ref.data(), free_auto.data(), ref.size() * sizeof(double)) == 0;
+        double mean_ref = 0, mean_fast = 0, mean_free = 0;
         for (double v : ref) mean_ref += v;
         for (double v : fast) mean_fast += v;
+        for (double v : free_fast) mean_free += v;
         std::printf("%s\"fog%d\": {\"rc\": [%d, %d, %d], \"exact\": %s, \"auto_used_fast\": %s, \"auto_identical\": %s, \"fast_identical\": %s, "
                     "\"mean_ref\": %.6f, \"mean_fast\": %.6f, \"two_devices_identical\": %s, \"three_devices_identical\": %s, \"bytes_identical\": %s, "
+                    "\"free_exact\": %s, \"free_auto_used_fast\": %s, \"free_auto_identical\": %s, \"free_fast_identical\": %s, \"mean_free\": %.6f, "
                     "\"progress_calls\": %d, \"progress_monotone\": %s, \"progress_reached_total\": %s}",
                     fog ? ", " : "", fog, rc0, rc1, rc2, exact ? "true" : "false", auto_used_fast ? "true" : "false", same_auto ? "true" : "false",
                     same_fast ? "true" : "false", mean_ref / ref.size(), mean_fast / fast.size(), same_two ? "true" : "false", same_three ? "true" : "false",
-                    same_bytes ? "true" : "false", log.calls, (log.monotone && first_monotone) ? "true" : "false", (log.total > 0 && log.last == log.total) ? "true" : "false");
+                    same_bytes ? "true" : "false", free_exact ? "true" : "false", free_auto_used_fast ? "true" : "false", same_free_auto ? "true" : "false",
+                    same_free_fast ? "true" : "false", mean_free / ref.size(), log.calls, (log.monotone && first_monotone) ? "true" : "false", (log.total > 0 && log.last == log.total) ? "true" : "false");
         ok = ok && rc0 == 0 && rc1 == 0 && rc2 == 0;
     }
     std::printf("}\n");

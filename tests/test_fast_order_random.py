@@ -109,3 +109,71 @@ def test_degenerate_scene_of_coincident_spheres_is_handled(rt, orc):
     got, _, cnt = orc.render(fast.desc_ptr, cam, 7, 4)
     assert np.array_equal(got, ref)
     assert cnt["sphere_tests"] > 0
+
+
+def random_fog_scene(seed):
+    """Spheres and constant media (bounded by spheres, some inside one another, one enclosing the camera) arranged the way
+    the reference's scenes are: bvh_nodes over parts of the world, plain lists around them, a medium listed twice."""
+    rnd = random.Random(seed)
+    b = DescBuilder()
+    mats = [b.lambertian((rnd.random(), rnd.random(), rnd.random())) for _ in range(3)]
+    mats += [b.metal((0.8, 0.7, 0.6), rnd.random() * 0.4), b.dielectric(1.5), b.light((4.0, 4.0, 3.5))]
+
+    def ball():
+        c = (rnd.uniform(-4, 4), rnd.uniform(-1, 3), rnd.uniform(-9, -2))
+        motion = (rnd.uniform(-0.3, 0.3), rnd.uniform(-0.2, 0.2), 0.0) if rnd.random() < 0.2 else (0.0, 0.0, 0.0)
+        return b.sphere(c, rnd.uniform(0.15, 0.9), rnd.choice(mats), motion)
+
+    def fog():
+        c = (rnd.uniform(-3, 3), rnd.uniform(-0.5, 2), rnd.uniform(-8, -3))
+        shell = b.sphere(c, rnd.uniform(0.6, 1.8), mats[4])
+        parts = [b.medium(shell, rnd.uniform(0.3, 2.5), (rnd.random(), rnd.random(), rnd.random()))]
+        if rnd.random() < 0.5:
+            parts.append(shell)        # the glass boundary is an object of the world too (main.cpp:301-303)
+        return parts
+
+    def group(n_balls, n_fogs):
+        members = [ball() for _ in range(n_balls)]
+        for _ in range(n_fogs):
+            members += fog()
+        rnd.shuffle(members)
+        return members
+
+    top = [b.sphere((0, -101, -5), 100.0, mats[0])]
+    top.append(b.bvh(group(rnd.randint(4, 12), rnd.randint(1, 2)), rnd))        # media deep inside a bvh_node
+    top.append(b.bvh(group(rnd.randint(3, 10), 0), rnd))                        # a bvh_node without any
+    top += group(rnd.randint(2, 5), rnd.randint(0, 1))                          # loose objects and media in the top-level list
+    if rnd.random() < 0.6:                                                      # a thin haze around everything, camera included
+        top.append(b.medium(b.sphere((0, 0, 0), 60.0, mats[4]), 0.02, (1, 1, 1)))
+    if rnd.random() < 0.5:
+        top.append(b.list(group(2, 1)))                                         # a nested list with a medium
+    if rnd.random() < 0.3:
+        top.append(b.bvh([m for m in fog() if True][:1], rnd))                  # a bvh_node of one medium: tested twice (bvh.h:30-32)
+    rnd.shuffle(top)
+    root = b.list(top)
+    if rnd.random() < 0.5:                                                      # main.cpp:442: the whole world inside one bvh_node
+        root = b.list([b.bvh(top, rnd)])
+    return b.finish(root)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_fog_scenes_render_identically_in_the_fast_order(rt, orc, seed):
+    """constant_medium::hit draws inside hit() (constant_medium.h:40) and runs only when the bvh_nodes above it let the ray
+    through with the interval as it stands at that moment: the optimiser keeps media and the groups above them as the
+    reference has them and re-groups the rest, so the oracle's image of its output must still be the reference order's, bit
+    for bit, draws and medium tests included.  With free_media_order the pass says the image may differ."""
+    scene = random_fog_scene(4000 + seed)
+    cam = look_at_camera(rt)
+    ref, ref8, rc = orc.render(scene.desc_ptr, cam, 7, 4)
+    assert rc["medium_tests"] > 0
+    for eye in (cam.center, None):
+        fast = rt.FastOrderScene(scene, eye)
+        assert fast.exact and fast.info["has_media"] and fast.info["n_kept_nodes"] >= 1
+        got, got8, gc = orc.render(fast.desc_ptr, cam, 7, 4)
+        assert np.array_equal(got, ref) and np.array_equal(got8, ref8), f"seed {seed}: max diff {np.abs(got - ref).max()}"
+        for k in ("segments", "surface_hits", "rng_draws", "medium_tests"):
+            assert gc[k] == rc[k], k
+    free = rt.FastOrderScene(scene, cam.center, free_media_order=True)
+    assert not free.exact and free.info["n_kept_nodes"] == 0
+    got, _, gc = orc.render(free.desc_ptr, cam, 7, 4)
+    assert gc["samples"] == rc["samples"] and abs(got.mean() - ref.mean()) < 0.1 * ref.mean() + 1e-3

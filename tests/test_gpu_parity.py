@@ -290,9 +290,9 @@ def test_config1_and_config3_reduced_spp_properties(rt, orc, renderer, scenes):
 
 def test_config4_and_config5_full_resolution_reduced_spp_properties(rt, orc, renderer, scenes):
     """configs[3] (triangle mesh, 1920x1080) and configs[4] (book-2 final: media, Perlin, motion blur, image texture,
-    instances; 1920x1080) at full resolution and 8 of their 256 / 1000 spp, in the order and with the kernels bench.py
-    times there (reference order; boxes-in-LDS kernels, the programs do not fit LDS): exact per-pixel agreement with the
-    oracle on random pixels, finiteness, and brightness bounds the scenes imply."""
+    instances; 1920x1080) at full resolution and 8 of their 256 / 1000 spp, in the reference order (boxes-in-LDS kernels,
+    the programs do not fit LDS) and in the fast order bench.py times: exact per-pixel agreement with the oracle on random
+    pixels, finiteness, brightness bounds the scenes imply, and the same doubles from both orders."""
     scene = scenes("mesh")
     cam = scene.camera(0, 0, 8, 0)
     assert (cam.image_width, cam.image_height, cam.max_depth) == (1920, 1080, 10)
@@ -311,6 +311,12 @@ def test_config4_and_config5_full_resolution_reduced_spp_properties(rt, orc, ren
     assert "1151u" in renderer.kernel_name()
     img = _full_size_checks(rt, orc, renderer, scene, cam, n_probe=32)
     assert img.max() <= 7.0 + 1e-9 and img.mean() > 0.005    # nothing is brighter than the light (emit 7, main.cpp:292)
+    # ... and as bench.py times it: the fast order with the two media and the groups above them kept as the reference
+    # has them (exact boxes throughout, boxes-in-LDS kernel) -- the very same doubles, 2 M pixels x 8 samples
+    info = renderer.upload_fast(scene, cam.center)
+    assert info["exact"] and info["has_media"] and info["n_kept_nodes"] > 0 and "1151u" in renderer.kernel_name()
+    fast = _full_size_checks(rt, orc, renderer, scene, cam, n_probe=8, probe_seed=5)
+    assert np.array_equal(fast, img)
 
 
 def test_device_hit_records_match_reference_known_answers(rt, renderer, tmp_path):
@@ -370,9 +376,12 @@ def test_fast_order_on_the_device(rt, orc, renderer, scenes, case):
     feat = int(renderer.kernel_name().split(",")[1].strip().rstrip("u"))
     # every f64 kernel of the fast order culls with f32 boxes (F_F32_BOX = 256): the MIXED program of sphere-only scenes
     # (feat == 256) or the COMPACT program of the other families; variant bit 20 keeps the f64 boxes of the slot program
-    assert (feat & 256) or name == "book2_final"     # (a full-feature scene whose COMPACT program does not fit LDS stays on the slot program)
+    # ... except with a constant_medium: the boxes above it are the reference's own and decide whether it draws, so every
+    # slab test stays aabb::hit as written (full-feature kernel, neither F_FMA_BOX = 128 nor F_F32_BOX)
+    has_media = fast.info["has_media"]
+    assert (feat & ~1024) == 127 if has_media else (feat & 256)
     slot_feat = int(renderer.kernel_name(variant=1 << 20).split(",")[1].strip().rstrip("u"))
-    assert not (slot_feat & 256) and ((slot_feat & 128) or (slot_feat & ~(512 | 1024)) == 69)
+    assert not (slot_feat & 256) and ((slot_feat & 128) or (slot_feat & ~(512 | 1024)) == 69 or (has_media and (slot_feat & ~1024) == 127))
     fused, fused8, fcnt = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, count=True)
     fused_fast, _, _ = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64)
     assert np.array_equal(fused, gpu) and np.array_equal(fused8, gpu8) and np.array_equal(fused_fast, gpu)
@@ -384,14 +393,20 @@ def test_fast_order_on_the_device(rt, orc, renderer, scenes, case):
     slot_fast, _, _ = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, variant=1 << 20)
     in_global, _, _ = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, variant=1)
     assert np.array_equal(slot_fast, gpu) and np.array_equal(in_global, gpu)
-    if not fast.info["has_media"]:
-        renderer.upload(scene)
-        base, base8, bcnt = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, count=True)
-        assert np.array_equal(gpu, base) and np.array_equal(gpu8, base8)
-        golden = np.load(os.path.join(GOLDEN, f"img_{name}.npz"), allow_pickle=False)
-        assert rmse(gpu, golden["linear"]) < F64_RMSE_BOUND and np.array_equal(gpu8, golden["rgb8"])
-        for key in ("samples", "segments", "surface_hits", "rng_draws"):
-            assert counters[key] == bcnt[key], key
+    assert fast.exact   # media included: they keep their place in the reference's order
+    renderer.upload(scene)
+    base, base8, bcnt = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, count=True)
+    assert np.array_equal(gpu, base) and np.array_equal(gpu8, base8)
+    golden = np.load(os.path.join(GOLDEN, f"img_{name}.npz"), allow_pickle=False)
+    assert rmse(gpu, golden["linear"]) < F64_RMSE_BOUND and np.array_equal(gpu8, golden["rgb8"])
+    for key in ("samples", "segments", "surface_hits", "rng_draws", "medium_tests"):
+        assert counters[key] == bcnt[key], key
+    if has_media:   # opts.free_media_order: the fused / f32 tests are back, the image is another sample of the same estimator
+        info = renderer.upload_fast(scene, cam.center, free_media_order=True)
+        assert not info["exact"] and int(renderer.kernel_name().split(",")[1].strip().rstrip("u")) & (128 | 256)
+        free, _, _ = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64)
+        assert abs(free.mean() - gpu.mean()) < 0.08 * gpu.mean() + 1e-3
+        assert name == "single_fog" or not np.array_equal(free, gpu)   # (a world of one medium has only one order)
 
 
 def test_fast_order_full_resolution_book1_is_bit_identical_and_cheaper(rt, renderer, scenes):
@@ -521,8 +536,9 @@ def test_random_soups_on_the_device(rt, orc, renderer, seed, triangles):
 def test_cpp_camera_render_through_the_drop_in_api(rt, tmp_path):
     """The C++ side of the boundary end to end (host/rtk_camera.h): a reference-style program builds its scene with the
     drop-in classes and calls camera::render_to.  auto_order must pick the fast order exactly when it is bit-identical
-    (no constant_medium) and then give the very same doubles as reference_order; with a medium it must stay on the
-    reference order (identical again), while the forced fast order is only statistically the same image."""
+    and then give the very same doubles as reference_order -- with a constant_medium in the scene as well; only with
+    camera::free_media_order it must stay on the reference order (identical again), while the forced fast order is
+    statistically the same image."""
     import json
     import subprocess
 
@@ -537,9 +553,13 @@ def test_cpp_camera_render_through_the_drop_in_api(rt, tmp_path):
     verdict = json.loads(out.strip().splitlines()[-1])
     clear, fog = verdict["fog0"], verdict["fog1"]
     assert clear["rc"] == [0, 0, 0] and fog["rc"] == [0, 0, 0]
-    assert clear["exact"] and clear["auto_used_fast"] and clear["auto_identical"] and clear["fast_identical"]
-    assert not fog["exact"] and not fog["auto_used_fast"] and fog["auto_identical"]
-    assert abs(fog["mean_fast"] - fog["mean_ref"]) < 0.03 * fog["mean_ref"]
+    for v in (clear, fog):   # with a medium too: it keeps its place in the reference's order (rtk_optimize_opts.free_media_order = 0)
+        assert v["exact"] and v["auto_used_fast"] and v["auto_identical"] and v["fast_identical"]
+    # camera::free_media_order: nothing changes without a medium; with one the pass no longer claims exactness, auto_order
+    # stays on the reference order, and the forced fast order is another image of the same estimator
+    assert clear["free_exact"] and clear["free_auto_used_fast"] and clear["free_auto_identical"] and clear["free_fast_identical"]
+    assert not fog["free_exact"] and not fog["free_auto_used_fast"] and fog["free_auto_identical"] and not fog["free_fast_identical"]
+    assert abs(fog["mean_free"] - fog["mean_ref"]) < 0.03 * fog["mean_ref"]
     assert clear["mean_ref"] > 0.05
     # camera::devices = {0, 0} / {0, 0, 0}: render() splits the image itself (rtk_render_multi) -- same doubles, same bytes;
     # camera::progress is fed from the work-item counters and ends at the total (Camera.txt:102-106 prints a percentage)

@@ -21,7 +21,8 @@ cam = scene.camera(0, 0, spp, 0)
 r = rt.Renderer(0)
 fast = scene.fast_order(cam.center)
 use_fast = order == "fast" or (order == "auto" and fast.exact)  # same rule as bench.py
-r.upload_fast(scene, cam.center) if use_fast else r.upload(scene)
+prim_cost, free_media = float(os.environ.get("AB_PRIM_COST", "0")), os.environ.get("AB_FREE_MEDIA", "0") == "1"   # sweeps of the optimiser's knobs
+r.upload_fast(scene, cam.center, prim_cost_scale=prim_cost, free_media_order=free_media) if use_fast else r.upload(scene)
 print(f"order: {'fast (rtk_scene_upload_fast)' if use_fast else 'reference (bvh.h)'}", flush=True)
 dev = torch.device("cuda", 0)
 H, W = cam.image_height, cam.image_width

@@ -1129,7 +1129,7 @@ RTK_DEV int popcount64(unsigned long long m) {
 // library): s_memtime stamps at the scheduler's phase boundaries; per phase the wave adds its cycles,
 // step count and active-lane count to counters[3*phase .. 3*phase+2].  The product build has none of it.
 #ifdef RTK_PROFILE
-#define RTK_PROF_DECL unsigned long long prof_t[6] = {0, 0, 0, 0, 0, 0}, prof_n[6] = {0, 0, 0, 0, 0, 0}, prof_l[6] = {0, 0, 0, 0, 0, 0}; \
+#define RTK_PROF_DECL unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_n[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_l[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
     unsigned long long prof_prev = __builtin_amdgcn_s_memtime();                                                                       \
     const unsigned long long prof_wall0 = wall_clock64();                                                                              \
     unsigned long long prof_wall_empty = 0, prof_chunk_t0 = 0;
@@ -1159,10 +1159,11 @@ RTK_DEV int popcount64(unsigned long long m) {
     }
 #define RTK_PROF_FLUSH                                                        \
     if (lane == 0)                                                            \
-        for (int ph_ = 0; ph_ < 6; ph_++) {                                   \
-            atomicAdd(&counters[3 * ph_], prof_t[ph_]);                       \
-            atomicAdd(&counters[3 * ph_ + 1], prof_n[ph_]);                   \
-            atomicAdd(&counters[3 * ph_ + 2], prof_l[ph_]);                   \
+        for (int ph_ = 0; ph_ < 8; ph_++) { /* phases 6, 7 (parts of the shade step) live at [25..30] */ \
+            const int at_ = ph_ < 6 ? 3 * ph_ : 25 + 3 * (ph_ - 6);          \
+            atomicAdd(&counters[at_], prof_t[ph_]);                           \
+            atomicAdd(&counters[at_ + 1], prof_n[ph_]);                       \
+            atomicAdd(&counters[at_ + 2], prof_l[ph_]);                       \
         }                                                                     \
     if (lane == 0) { /* wave lifetimes on the 100 MHz wall clock: [18] sum, [19] max, [20] sum of the time after the queue ran dry, [21] its max, [22] waves, [23] 2^62 - first start, [24] last end */ \
         const unsigned long long end_ = wall_clock64();                       \
@@ -1587,7 +1588,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                         L.kind = k;
                     }
                 }
-                if (popcount64(__ballot(k == OP_SPHERE)) >= sphere_min) {
+                if ([[maybe_unused]] const int n_ride = popcount64(__ballot(k == OP_SPHERE)); n_ride >= sphere_min) {
                     if (k == OP_SPHERE) {
                         if constexpr (SPLIT) cur = head_at(L.pc);
                         if constexpr (COMPACT) step_sphere_compact<XF>(L, cur, prog + L.pc, cnt, tie);
@@ -1596,7 +1597,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                         fetch();
                         L.kind = k;
                     }
-                    RTK_PROF_MARK(2, 1, 0)
+                    RTK_PROF_MARK(2, 1, n_ride)
                 }
 #ifndef RTK_TRI_RIDE
 #define RTK_TRI_RIDE 16
@@ -1734,6 +1735,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                     }
                 }
             }
+            RTK_PROF_MARK(3, 1, n_shd)   // profile build: the shade step in three parts -- ray_color's body, begin_sample, begin_segment
             // 2. lanes that just finished take the next pixels of the wave's current work item right here, so that
             // their begin_sample / begin_segment is the code the continuing lanes execute anyway; a separate refill
             // round costs as much as a shade step and serves a dozen lanes.  Only what the current item still holds:
@@ -1766,6 +1768,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             }
             // 3. the next sample of the same or of the new pixel, then the next segment
             if (next_sample) begin_sample(L, cam, px_i, px_j, seed_hash, cnt);
+            RTK_PROF_MARK(6, 1, popcount64(__ballot(next_sample)))
             if (alive) {
                 if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0, MIXED>(L, cnt, extent);
                 else L.pc = end_pc;
@@ -1774,7 +1777,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
 #if RTK_AB_SHADE_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
-            RTK_PROF_MARK(3, 1, n_shd)
+            RTK_PROF_MARK(7, 1, popcount64(__ballot(alive)))
         } else {
             if (m_oth >> lane & 1ull) {
                 if constexpr (MIXED && !COMPACT) step_other_mixed(L, prog + L.pc, cnt, tie);

@@ -51,14 +51,15 @@ for k in range(3):
     e1.record(); e1.synchronize()
 ms = e0.elapsed_time(e1)
 raw = prof.cpu().numpy()
-v = raw[:18].reshape(6, 3).astype(float)
+import numpy as np
+v = np.concatenate([raw[:18], raw[25:31]]).reshape(8, 3).astype(float)
 total = v[:, 0].sum()
-names = ["refill+vote", "box step", "sphere step", "shade+regen", "other op", "quad/tri step"]
+names = ["refill+vote", "box step", "sphere step", "shade: ray_color", "other op", "quad/tri step", "shade: new sample", "shade: new segment"]
 print(f"{config} {'f64' if real == rt.RTK_REAL_F64 else 'f32'} {W}x{H}x{cam.samples_per_pixel}: {ms:.2f} ms (instrumented)")
-print(f"{'phase':14s} {'cycles %':>9s} {'steps':>14s} {'cyc/step':>9s} {'lanes/step':>10s}")
+print(f"{'phase':20s} {'cycles %':>9s} {'steps':>14s} {'cyc/step':>9s} {'lanes/step':>10s}")
 for n, (t, steps, lanes) in zip(names, v):
     if steps:
-        print(f"{n:14s} {100 * t / total:9.1f} {int(steps):14d} {t / steps:9.1f} {lanes / steps:10.1f}")
+        print(f"{n:20s} {100 * t / total:9.1f} {int(steps):14d} {t / steps:9.1f} {lanes / steps:10.1f}")
 waves = int(raw[22])
 if waves:
     span = (int(raw[24]) - ((1 << 62) - int(raw[23]))) / 100.0   # us

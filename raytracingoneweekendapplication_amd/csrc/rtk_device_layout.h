@@ -245,6 +245,7 @@ struct SceneView {  // device pointers, passed to the kernel by value
     const uint32_t* kind_words;
     const uint2* box_rank;
     int32_t n_cached_boxes, n_kind_words, n_rank_words;
+    int32_t n_perlins;
 };
 
 struct TileMap {  // which tiles this launch renders and where the pixels go
@@ -263,6 +264,9 @@ struct TileMap {  // which tiles this launch renders and where the pixels go
     int32_t order_in_lds, order_lds_offset;
     // F_LDS_BOXES kernels: byte offset of the material table staged behind the box tables (0 = materials stay in memory)
     int32_t mats_lds_offset;
+    // ... and of the Perlin tables (9 KB each in f64: 256 gradient vectors + three permutations) when they fit as well
+    // (0 = they stay in memory): perlin::turb reads 7 x (6 permutation entries + 8 gradients) through a dependent index
+    int32_t perlin_lds_offset;
 };
 
 // Indices into the uint64 work-counter block (same order as rtk_work_counters).

@@ -1282,6 +1282,15 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             mats = reinterpret_cast<const MaterialRec<real>*>(lds_program + tmap.mats_lds_offset);
         }
 #endif
+        if constexpr ((FEAT & F_TEXTURE) != 0) {  // the Perlin tables too, when the launcher found room (tmap.perlin_lds_offset > 0)
+            if (tmap.perlin_lds_offset > 0) {
+                const int n16 = sc.n_perlins * int(sizeof(PerlinRec<real>) / 16);
+                const uint4* __restrict__ psrc = reinterpret_cast<const uint4*>(sc.perlins);
+                uint4* pdst = reinterpret_cast<uint4*>(lds_program + tmap.perlin_lds_offset);
+                for (int k = threadIdx.x; k < n16; k += blockDim.x) pdst[k] = psrc[k];
+                sc.perlins = reinterpret_cast<const PerlinRec<real>*>(lds_program + tmap.perlin_lds_offset);  // texture_value reads through sc
+            }
+        }
         __syncthreads();
         lds_boxes = reinterpret_cast<const BoxCacheRec*>(lds_program);
         lds_kinds = kdst;
@@ -2030,12 +2039,23 @@ static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>* c
     size_t lds = IN_LDS ? lds_image_bytes(sc, FEAT) : ((FEAT & F_LDS_BOXES) ? split_lds_bytes(sc, FEAT) : 0);
     TileMap tm = tmap;
     tm.mats_lds_offset = 0;
+    tm.perlin_lds_offset = 0;
     if constexpr ((FEAT & F_LDS_BOXES) != 0) {  // boxes-in-LDS kernels: the material table too, if it is small and there is room
         const size_t mat_bytes = size_t(sc.n_materials) * sizeof(MaterialRec<real>);
         const size_t at = (lds + 15) & ~size_t(15);
         if (RTK_SPLIT_MATERIALS_IN_LDS && mat_bytes <= 16 * 1024 && at + mat_bytes + 64 <= size_t(kLdsBytesPerCU)) {
             tm.mats_lds_offset = int32_t(at);
             lds = at + mat_bytes;
+        }
+#ifndef RTK_SPLIT_PERLIN_IN_LDS
+#define RTK_SPLIT_PERLIN_IN_LDS 1
+#endif
+        // ... and the Perlin tables (book-2's noise sphere: 7.8 % of the C5 frame went into perlin::turb's dependent gathers from memory)
+        const size_t perlin_bytes = size_t(sc.n_perlins) * sizeof(PerlinRec<real>);
+        const size_t pat = (lds + 15) & ~size_t(15);
+        if (RTK_SPLIT_PERLIN_IN_LDS && (FEAT & F_TEXTURE) != 0 && perlin_bytes > 0 && pat + perlin_bytes + 64 <= size_t(kLdsBytesPerCU)) {
+            tm.perlin_lds_offset = int32_t(pat);
+            lds = pat + perlin_bytes;
         }
     }
     // room for the tile order behind the program?  (never at the price of a second resident workgroup's LDS)

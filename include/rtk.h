@@ -265,9 +265,11 @@ int rtk_scene_validate(const rtk_scene_desc* scene, int32_t* n_program_ops);
  * The closest hit of every ray is preserved and exact ties go to the primitive
  * the reference would have kept (rtk_node.c ranks), so the image is bit-identical
  * (info->exact = 1).  A constant_medium draws a random number inside hit()
- * (constant_medium.h:40), and whether hit() runs depends on what the reference
- * visited before it: media, and the groups above them, therefore keep the
- * reference's structure and only what holds no medium is re-grouped (see
+ * (constant_medium.h:40), so it must be called with the interval the reference
+ * calls it with: media (and instances holding one) keep their position in the
+ * reference's visiting order and only the runs of objects between them are
+ * re-grouped -- the bvh_nodes above a medium need not be kept, because a medium
+ * the reference skips there returns false before it draws anyway (see
  * opts->free_media_order).  With triangles see rtk_optimize_info.has_triangles.
  * The work counters differ by design.  *out_scene borrows every table of `scene` except nodes,
  * list_children and bvh_boxes: keep `scene` alive while it is in use, release it
@@ -280,11 +282,11 @@ typedef struct rtk_optimize_opts {
                              * for scenes with quads; scenes of spheres and triangles are re-grouped at 1.5 (then 1.4,
                              * 1.2) as long as the resulting program still fits one CU's LDS (more boxes, fewer primitive
                              * tests: C4 66.0 -> 63.5 ms) */
-    int32_t free_media_order; /* 0 (default): a constant_medium, and every bvh_node / hittable_list above one, keeps the
-                               * reference's structure and order, so the medium meets the same interval and draws the same
-                               * random numbers as in the reference: the image stays bit-identical (info->exact = 1).
-                               * != 0: media are re-grouped like any other object -- somewhat fewer box tests, but the
-                               * order of the draws inside constant_medium::hit changes and parity becomes statistical */
+    int32_t free_media_order; /* 0 (default): a constant_medium keeps its position in the reference's visiting order -- it is
+                               * called after exactly the objects that precede it there -- so it meets the same interval
+                               * and draws the same random numbers as in the reference: the image stays bit-identical
+                               * (info->exact = 1).  != 0: media are re-grouped like any other object; the order of the
+                               * draws inside constant_medium::hit changes and parity becomes statistical */
     int32_t _pad;
 } rtk_optimize_opts;
 
@@ -294,7 +296,7 @@ typedef struct rtk_optimize_info {
     int32_t has_triangles;      /* triangle::hit's float determinant (triangle.h:72,77): identical except where the
                                  * reference's own boxes cull a hit that triangle::hit accepts (order-dependent) */
     int32_t n_bvh_nodes_in, n_bvh_nodes_out;
-    int32_t n_kept_nodes;       /* bvh_node / hittable_list nodes kept as the reference has them because a medium lies below */
+    int32_t n_ordered_items;    /* media, and instances holding one, that kept their position in the reference's order */
     double expected_cost;       /* SAH estimate, in slab tests, of one closest-hit query */
     double box_margin;          /* every new box is grown by this much (2^-40 of the scene extent) */
 } rtk_optimize_info;

@@ -79,7 +79,7 @@ class OptimizeOpts(C.Structure):
 
 class OptimizeInfo(C.Structure):
     _fields_ = [("exact", C.c_int32), ("has_media", C.c_int32), ("has_triangles", C.c_int32),
-                ("n_bvh_nodes_in", C.c_int32), ("n_bvh_nodes_out", C.c_int32), ("n_kept_nodes", C.c_int32),
+                ("n_bvh_nodes_in", C.c_int32), ("n_bvh_nodes_out", C.c_int32), ("n_ordered_items", C.c_int32),
                 ("expected_cost", C.c_double), ("box_margin", C.c_double)]
 
 
@@ -89,7 +89,7 @@ def _optimize_opts(eye, max_leaf, prim_cost_scale, free_media_order) -> Optimize
 
 def _optimize_info(info: OptimizeInfo) -> dict:
     return {"exact": bool(info.exact), "has_media": bool(info.has_media), "has_triangles": bool(info.has_triangles),
-            "n_bvh_nodes_in": info.n_bvh_nodes_in, "n_bvh_nodes_out": info.n_bvh_nodes_out, "n_kept_nodes": info.n_kept_nodes,
+            "n_bvh_nodes_in": info.n_bvh_nodes_in, "n_bvh_nodes_out": info.n_bvh_nodes_out, "n_ordered_items": info.n_ordered_items,
             "expected_cost": info.expected_cost, "box_margin": info.box_margin}
 
 

@@ -498,8 +498,7 @@ static void build_compact_program(const rtk_scene_desc& sc, const Program& prog,
 }
 
 template <typename real>
-int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScene<real>& out, bool fast_order = false, bool want_mixed = false, double eye_extent = 0.0,
-                       bool culling_boxes = true) {
+int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScene<real>& out, bool fast_order = false, bool want_mixed = false, double eye_extent = 0.0) {
     out.release();
     // ---- the fused traversal program: one or more slots per op, skip links
     // translated from op indices to slot indices
@@ -739,9 +738,7 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
         if (any && (rc = out.upload(rank_of_slot, &out.view.tie_rank_slot)) != RTK_OK) return rc;
     }
     if constexpr (sizeof(real) == 8) {
-        if (!culling_boxes) {
-            // exact boxes asked for: the slot program only
-        } else if (fast_order && want_mixed) {
+        if (fast_order && want_mixed) {
             std::vector<MixedHead> units;
             std::vector<uint32_t> ranks;
             build_mixed_program(sc, prog, eye_extent, units, ranks, out.view.extent);
@@ -967,7 +964,7 @@ enum UploadOrder {
     kOrderReference,  // the caller's own boxes: aabb::hit as written (aabb.h:61-85)
     kOrderFast,       // rtk_scene_optimize output, every box grown by the pass's margin: fused / f32 culling tests
 };
-static int upload_scene(rtk_ctx* ctx, const rtk_scene_desc* scene, UploadOrder order, double eye_extent = 0.0, bool free_media_order = false);
+static int upload_scene(rtk_ctx* ctx, const rtk_scene_desc* scene, UploadOrder order, double eye_extent = 0.0);
 
 int rtk_scene_upload(rtk_ctx* ctx, const rtk_scene_desc* scene) {
     if (!ctx || !scene) return fail(RTK_ERR_INVALID, "rtk_scene_upload: null argument");
@@ -982,7 +979,7 @@ int rtk_scene_upload_fast(rtk_ctx* ctx, const rtk_scene_desc* scene, const rtk_o
     // every box of `fast` was grown by rtk_scene_optimize's margin: the kernels may use the fused slab test
     double eye_extent = 0.0;
     if (opts && opts->has_eye) eye_extent = std::max(std::fabs(opts->eye.x), std::max(std::fabs(opts->eye.y), std::fabs(opts->eye.z)));
-    rc = upload_scene(ctx, fast, kOrderFast, eye_extent, opts && opts->free_media_order != 0);
+    rc = upload_scene(ctx, fast, kOrderFast, eye_extent);
     rtk_scene_optimized_free(fast);
     return rc;
 }
@@ -991,7 +988,7 @@ int rtk_scene_upload_optimized(rtk_ctx* ctx, const rtk_scene_desc* optimized, co
     if (!ctx || !optimized) return fail(RTK_ERR_INVALID, "rtk_scene_upload_optimized: null argument");
     double eye_extent = 0.0;
     if (opts && opts->has_eye) eye_extent = std::max(std::fabs(opts->eye.x), std::max(std::fabs(opts->eye.y), std::fabs(opts->eye.z)));
-    return upload_scene(ctx, optimized, kOrderFast, eye_extent, opts && opts->free_media_order != 0);
+    return upload_scene(ctx, optimized, kOrderFast, eye_extent);
 }
 
 // Everything that can be decided without a device: table validation and the compilation of the traversal program.
@@ -1021,16 +1018,14 @@ int rtk_scene_validate(const rtk_scene_desc* scene, int32_t* n_program_ops) {
     }
 }
 
-static int upload_scene(rtk_ctx* ctx, const rtk_scene_desc* scene, UploadOrder order, double eye_extent, bool free_media_order) {
+static int upload_scene(rtk_ctx* ctx, const rtk_scene_desc* scene, UploadOrder order, double eye_extent) {
     Program prog;
     int rc = compile_scene(scene, prog);
     if (rc != RTK_OK) return rc;
-    // Fast order with a constant_medium kept in the reference's place (rtk_scene_optimize, keep_group): the boxes above the
-    // medium are the reference's own, ungrown, and their tests decide whether the medium draws -- so every slab test stays
-    // aabb::hit as written (no fused test, no f32 culling boxes); the tie ranks still apply.
+    // (Media scenes included: rtk_scene_optimize keeps a medium's POSITION in the reference's order; the boxes around it may
+    // be as conservative as any other -- a medium the reference would have skipped returns false before it draws.)
     const bool fast_order = order == kOrderFast;
-    const bool exact_boxes = fast_order && (prog.features & F_MEDIA) != 0 && !free_media_order;
-    uint32_t hierarchy_flags = (fast_order && !exact_boxes) ? uint32_t(F_FMA_BOX) : 0u;
+    uint32_t hierarchy_flags = fast_order ? uint32_t(F_FMA_BOX) : 0u;
     for (int32_t i = 0; i < scene->n_materials; i++) {
         const rtk_material& m = scene->materials[i];
         if (m.kind == RTK_MAT_DIFFUSE_LIGHT || m.kind == RTK_MAT_ISOTROPIC || m.kind == RTK_MAT_SPECULAR) prog.features |= F_EXOTIC_MAT;
@@ -1049,7 +1044,7 @@ static int upload_scene(rtk_ctx* ctx, const rtk_scene_desc* scene, UploadOrder o
     // sphere-only scenes in the fast order additionally get the MIXED program (f32 culling boxes) for the f64 kernels
     // ... every other scene of the fast order the COMPACT program (f32 culling boxes, f64 primitives, 16-byte units)
     const bool want_mixed = fast_order && prog.features == kFeatLean && prog.chains.size() <= 1;
-    if ((rc = build_device_scene<double>(*scene, prog, ctx->scene64, fast_order, want_mixed, eye_extent, !exact_boxes)) != RTK_OK) return rc;
+    if ((rc = build_device_scene<double>(*scene, prog, ctx->scene64, fast_order, want_mixed, eye_extent)) != RTK_OK) return rc;
     if ((rc = build_device_scene<float>(*scene, prog, ctx->scene32, fast_order)) != RTK_OK) return rc;
     ctx->features = prog.features | hierarchy_flags;
     ctx->n_ops = int32_t(prog.ops.size());

@@ -17,7 +17,7 @@
 // What is preserved: the closest hit of every ray, hence every pixel bit for bit
 // (the RNG stream of a sample does not depend on the visiting order unless a
 // medium draws inside hit(), constant_medium.h:40 -- and media keep their place in
-// the reference's order, see keep_group; only with opts.free_media_order are they
+// the reference's order, see ordered_group; only with opts.free_media_order are they
 // re-grouped too, parity then is statistical and rtk_optimize_info.exact says so).
 // What changes: the work counters (fewer box tests).  Triangles: triangle::hit scales
 // its hit distance by a float reciprocal of a float determinant (triangle.h:72,77),
@@ -25,14 +25,14 @@
 // exact box; whether the reference's own boxes let such a hit through depends on
 // its visiting order, which no other hierarchy can reproduce.  Triangle boxes are
 // grown so that no accepted hit is ever culled here (the fast order finds the
-// closest of ALL hits triangle::hit accepts), and exact is reported as 0 for
-// scenes with triangles: on the C4 mesh scene 1 sample in 5.3e8 took a different
+// closest of ALL hits triangle::hit accepts; rtk_optimize_info.has_triangles
+// flags such scenes): on the C4 mesh scene 1 sample in 5.3e8 took a different
 // path before the boxes were grown.  Ties: two different primitives
 // hit at exactly the same t are resolved by visiting order in the reference
 // (strict `surrounds` for spheres, sphere.h:44-48; inclusive `contains` for
-// quads/triangles, quad.h:39, triangle.h:91); the re-ordered hierarchy may
-// resolve such a tie differently.  None of the BASELINE scenes has one (tested
-// by whole-image equality against the reference order).
+// quads/triangles, quad.h:39, triangle.h:91); every primitive node of the output
+// carries its rank in the reference's order (rtk_node.c) and the kernels and the
+// oracle resolve a tie by those ranks, i.e. the way the reference does.
 //
 // Boxes: every primitive box is computed the way the reference computes it
 // (sphere.h:17,24-26; quad.h:21-25; triangle.h:59; hittable.h:43,75-98;
@@ -113,8 +113,8 @@ struct Optimizer {
     std::vector<char> memo_media;    // the subtree of that input node contains a constant_medium
     std::vector<int32_t> ref_rank;   // input primitive node -> 1 + rank of its first visit in the reference order (0: never visited)
     std::vector<char> holds_medium;  // input node -> 1: a constant_medium is reachable from it, 0: none (scan_media)
-    bool keep_media_order = true;    // media and every group above one keep the reference's structure (see keep_group)
-    int32_t n_kept = 0;
+    bool keep_media_order = true;    // media keep their place in the reference's visiting order (see ordered_group)
+    int32_t n_ordered = 0;
     bool failed = false;
     bool has_media = false;
     double margin = 0.0, tri_margin = 0.0;
@@ -253,7 +253,7 @@ struct Optimizer {
             case RTK_NODE_LIST:
             case RTK_NODE_BVH: {
                 if (keep_media_order && holds_medium[size_t(node)]) {
-                    o = keep_group(node, box, cost, depth);
+                    o = ordered_group(node, box, cost, depth);
                     memo_media[node] = 1;
                     has_media = true;
                     break;
@@ -489,71 +489,92 @@ struct Optimizer {
         return build_items(items, box, cost);
     }
 
-    // A group that holds a constant_medium, directly or further down, keeps the reference's own shape.  Whether
-    // constant_medium::hit runs for a ray -- and draws its random number (constant_medium.h:40) -- is decided by the slab
-    // tests of the bvh_nodes above it against the interval as it stands when the reference gets there (bvh.h:64-69), i.e.
-    // by everything the reference visited BEFORE.  So such a bvh_node stays a bvh_node with its own box, children in the
-    // reference's order, and such a hittable_list stays a list in order; what hangs off them without a medium inside is
-    // re-grouped freely (its closest hit within a given interval does not depend on the visiting order), and neighbouring
-    // medium-free children of a kept list are re-grouped together.  The medium then meets the same interval as in the
-    // reference, draws the same numbers, and the image stays bit-identical.
-    int32_t keep_group(int32_t node, Box& box, double& cost, int depth) {
-        const rtk_node n = in.nodes[node];
-        n_kept++;
-        if (n.kind == RTK_NODE_BVH) {
-            n_bvh_in++;
-            if (n.c < 0 || n.c >= in.n_bvh_boxes || !in.bvh_boxes) return fail_node();
-            Box ba, bb;
-            double ca = 0, cb = 0;
-            const int32_t a = convert(n.a, ba, ca, depth + 1);
-            if (a < 0) return -1;
-            const int32_t b = convert(n.b, bb, cb, depth + 1);  // a span of one lists the object twice (bvh.h:30-32): memoised, visited twice as in the reference
-            if (b < 0) return -1;
-            const rtk_aabb own = in.bvh_boxes[n.c];  // verbatim: its slab test decides what the medium below sees
-            out.boxes.push_back(own);
-            box = Box{{own.xmin, own.ymin, own.zmin}, {own.xmax, own.ymax, own.zmax}};
-            cost = kBoxCost + ca + cb;
-            return push_node(RTK_NODE_BVH, a, b, int32_t(out.boxes.size()) - 1);
-        }
-        if (n.a < 0 || n.b < 0 || int64_t(n.a) + n.b > in.n_list_children) return fail_node();
-        std::vector<int32_t> kept;
+    // A group that holds a constant_medium, directly or further down.  constant_medium::hit draws a random number
+    // (constant_medium.h:40), so for the image to stay bit-identical a medium must be called with the very interval the
+    // reference calls it with.  That interval is (0.001, closest hit so far), and "so far" means: among everything that
+    // precedes the medium in the reference's visiting order -- hittable_list children in order, a bvh_node's left then
+    // right (hittable_list.h:29-33, bvh.h:68-69).  The bvh_nodes above the medium do not matter beyond that order: when one
+    // of their slab tests fails, the reference skips the medium, but a medium called in that situation returns false
+    // BEFORE it draws -- its boundary lies inside that box, so either the ray misses the boundary (constant_medium.h:23,26)
+    // or enters it beyond the closest hit so far / leaves it before 0.001, and `rec1.t >= rec2.t` ends the call
+    // (constant_medium.h:31-34).  So the group is flattened into the reference's SEQUENCE: runs of medium-free objects,
+    // each re-grouped freely (its closest hit within a given interval does not depend on the visiting order), separated by
+    // the ordered items -- the media, and the instances that hold one -- in their reference order.  Every medium then
+    // meets the same interval as in the reference, draws the same numbers, and the image stays bit-identical (checked
+    // with boxes above the media grown by up to 1e6: same images, same draws; only the count of medium calls changes).
+    struct Sequence {
+        struct Entry {
+            int32_t node;
+            Box box;
+            double cost;
+            bool ordered;
+        };
+        std::vector<Entry> entries;
         std::vector<Item> run;
         std::unordered_set<int32_t> present;
-        box = Box::empty();
-        cost = 0;
-        auto close_run = [&]() {
-            if (run.empty()) return true;
-            Box rb;
-            double rc = 0;
-            const int32_t g = build_items(run, rb, rc);
-            if (g < 0) return false;
-            kept.push_back(g);
-            box.grow(rb);
-            cost += rc;
-            run.clear();
-            present.clear();
+    };
+    bool close_run(Sequence& q) {
+        if (q.run.empty()) return true;
+        Box rb;
+        double rc = 0;
+        const int32_t g = build_items(q.run, rb, rc);
+        if (g < 0) return false;
+        q.entries.push_back({g, rb, rc, false});
+        q.run.clear();
+        q.present.clear();  // (an object listed again after a medium is tested again, as in the reference)
+        return true;
+    }
+    bool walk_ordered(int32_t node, Sequence& q, int depth) {
+        if (failed || node < 0 || node >= in.n_nodes || depth > 4096) return !(failed = true);
+        if (!holds_medium[size_t(node)]) return gather(node, q.run, q.present, depth);
+        const rtk_node n = in.nodes[node];
+        if (n.kind == RTK_NODE_LIST) {
+            if (n.a < 0 || n.b < 0 || int64_t(n.a) + n.b > in.n_list_children) return !(failed = true);
+            for (int32_t k = 0; k < n.b; k++)
+                if (!walk_ordered(in.list_children[n.a + k], q, depth + 1)) return false;
             return true;
-        };
-        for (int32_t k = 0; k < n.b; k++) {
-            const int32_t child = in.list_children[n.a + k];
-            if (child < 0 || child >= in.n_nodes) return fail_node();
-            if (!holds_medium[size_t(child)]) {
-                if (!gather(child, run, present, depth + 1)) return -1;
-                continue;
-            }
-            if (!close_run()) return -1;
-            Box cb;
-            double cc = 0;
-            const int32_t o = convert(child, cb, cc, depth + 1);
-            if (o < 0) return -1;
-            kept.push_back(o);
-            box.grow(cb);
-            cost += cc;
         }
-        if (!close_run()) return -1;
+        if (n.kind == RTK_NODE_BVH) {  // a span of one lists its object twice (bvh.h:30-32): walked twice, as the reference visits it
+            n_bvh_in++;
+            return walk_ordered(n.a, q, depth + 1) && walk_ordered(n.b, q, depth + 1);
+        }
+        // a medium, or an instance transform with a medium inside: an ordered item
+        if (!close_run(q)) return false;
+        Box b;
+        double c = 0;
+        const int32_t o = convert(node, b, c, depth + 1);
+        if (o < 0) return false;
+        q.entries.push_back({o, b, c, true});
+        n_ordered++;
+        return true;
+    }
+    int32_t ordered_group(int32_t node, Box& box, double& cost, int depth) {
+        Sequence q;
+        if (!walk_ordered(node, q, depth) || !close_run(q)) return -1;
+        box = Box::empty();
+        for (const auto& e : q.entries) box.grow(e.box);
+        cost = 0;
+        std::vector<int32_t> members;
+        for (const auto& e : q.entries) {
+            int32_t member = e.node;
+            double c = e.cost;
+            // an ordered item much smaller than the group gets a slab test of its own (a box class step instead of the
+            // item's far dearer one for every ray that passes it by), like any expensive single item (represent)
+            const double pa = box.area();
+            const double boxed = kBoxCost + (pa > 0 ? std::min(1.0, e.box.area() / pa) : 1.0) * e.cost;
+            if (e.ordered && e.box.valid() && boxed < e.cost) {
+                const Box padded = grown(e.box, margin);
+                out.boxes.push_back(rtk_aabb{padded.lo[0], padded.hi[0], padded.lo[1], padded.hi[1], padded.lo[2], padded.hi[2]});
+                const int32_t nothing = push_node(RTK_NODE_LIST, int32_t(out.children.size()), 0, 0);
+                member = push_node(RTK_NODE_BVH, e.node, nothing, int32_t(out.boxes.size()) - 1);
+                c = boxed;
+            }
+            members.push_back(member);
+            cost += c;
+        }
         const int32_t first = int32_t(out.children.size());
-        out.children.insert(out.children.end(), kept.begin(), kept.end());
-        return push_node(RTK_NODE_LIST, first, int32_t(kept.size()), 0);
+        out.children.insert(out.children.end(), members.begin(), members.end());
+        return push_node(RTK_NODE_LIST, first, int32_t(members.size()), 0);
     }
 
     // Is a constant_medium reachable from each node?  (Iterative post-order; a cycle fails the pass.)
@@ -719,8 +740,7 @@ static int optimize_once(const rtk_scene_desc* scene, const rtk_optimize_opts* o
     // The root box holds the whole scene.  Every secondary ray starts on a surface, i.e. inside it, and so does every
     // primary ray when the eye lies inside it: a slab test from the inside cannot fail (the interval starts at 0.001,
     // Camera.txt:211), so the root's test is dropped -- its two children are visited unconditionally, in order.
-    const bool root_kept = op.keep_media_order && op.holds_medium[size_t(scene->root)];  // then its test is the reference's own: it stays
-    if (h->nodes[size_t(root)].kind == RTK_NODE_BVH && opts.has_eye && !root_kept) {
+    if (h->nodes[size_t(root)].kind == RTK_NODE_BVH && opts.has_eye) {
         const rtk_node rn = h->nodes[size_t(root)];
         const rtk_aabb& rb = h->boxes[size_t(rn.c)];
         const bool inside = opts.eye.x > rb.xmin && opts.eye.x < rb.xmax && opts.eye.y > rb.ymin && opts.eye.y < rb.ymax && opts.eye.z > rb.zmin &&
@@ -742,11 +762,11 @@ static int optimize_once(const rtk_scene_desc* scene, const rtk_optimize_opts* o
     h->desc.bvh_boxes = h->boxes.data();
     if (info) {
         // Closest hits are preserved, exact ties are resolved by the reference's ranks (rtk_node.c) and a medium meets the
-        // interval it meets in the reference (keep_group), so the image is the reference order's bit for bit unless the
+        // interval it meets in the reference (ordered_group), so the image is the reference order's bit for bit unless the
         // caller asked for the free order of media; has_triangles flags the one caveat left (see rtk.h)
         info->exact = (op.has_media && !op.keep_media_order) ? 0 : 1;
         info->has_media = op.has_media ? 1 : 0;
-        info->n_kept_nodes = op.n_kept;
+        info->n_ordered_items = op.n_ordered;
         info->has_triangles = op.has_triangles ? 1 : 0;
         info->n_bvh_nodes_in = int32_t(op.n_bvh_in);
         info->n_bvh_nodes_out = int32_t(h->boxes.size());
@@ -836,55 +856,47 @@ static void slot_program_counts(const rtk_scene_desc& d, size_t& n_slots, size_t
     }
 }
 
-// With opts->prim_cost_scale left at 0 ("automatic"), a scene of spheres and triangles is re-grouped with primitive tests
-// priced 1.5x dearer -- more, tighter boxes and fewer primitive tests, which is what pays once the kernels read everything
-// from LDS (C4: 66.0 -> 63.5 ms, C2: 21.31 -> 21.23) -- as long as its COMPACT program still fits one CU's LDS: a program
-// that has to leave LDS loses far more than the better hierarchy gains (C4 at 1.6x: 175 ms), so the scale steps down
-// (1.4, 1.2, 1.0) until it fits.  Scenes with quads keep 1.0 (the Cornell box is flat between 1.0 and 1.5 and worse in
-// between).  An explicit scale is honoured as given.
+// With opts->prim_cost_scale left at 0 ("automatic") the price of a primitive test relative to a slab test is chosen by
+// where the f64 kernels will find the traversal program (rtk_api.cpp / rtk_trace.hip):
+//  * a scene of spheres and triangles is re-grouped with primitive tests priced 1.5x dearer -- more, tighter boxes and fewer
+//    primitive tests, which is what pays once everything is read from LDS (C4: 66.0 -> 63.5 ms, C2: 21.31 -> 21.23) -- as
+//    long as its COMPACT program still fits one CU's LDS: a program that has to leave LDS loses far more than the better
+//    hierarchy gains (C4 at 1.6x: 175 ms), so the scale steps down (1.4, 1.2, 1.0) until it fits.  Scenes with quads start
+//    at 1.0 (the Cornell box is flat between 1.0 and 1.5 and worse in between);
+//  * a program that fits LDS in neither form (C5: 2 400 quads) runs from memory with its box records in LDS, if those
+//    fit: primitive tests are priced DOWN step by step (fewer, larger leaves: fewer boxes) until they do (C5: 3 100
+//    boxes at 1.0 = 173 KB; about 2 500 at 0.7 fit, 1 081 Msamples/s against 990 with the boxes in memory).
+// An explicit scale is honoured as given.
 int rtk_scene_optimize(const rtk_scene_desc* scene, const rtk_optimize_opts* opts_in, rtk_scene_desc** out_scene, rtk_optimize_info* info) {
     if (!scene || !out_scene) return RTK_ERR_INVALID;
     rtk_optimize_opts o;
     std::memset(&o, 0, sizeof o);
     if (opts_in) o = *opts_in;
-    if (!(o.prim_cost_scale > 0) && scene->n_quads == 0) {
-        for (double scale : {1.5, 1.4, 1.2}) {
-            o.prim_cost_scale = scale;
-            rtk_optimize_info local;
-            const int rc = optimize_once(scene, &o, out_scene, &local);
-            if (rc != RTK_OK) return rc;
-            if (compact_program_bytes(**out_scene) + 2048 <= size_t(160) * 1024) {
-                if (info) *info = local;
-                return RTK_OK;
-            }
-            rtk_scene_optimized_free(*out_scene);
-            *out_scene = nullptr;
-        }
-        o.prim_cost_scale = 0.0;
-    }
-    // A scene whose media keep their place renders from the slot program (exact boxes throughout, rtk_api.cpp).  When
-    // that program is too large for LDS, what matters is that at least its box records stay there: primitive tests
-    // are priced down step by step (fewer, larger leaves: fewer boxes) until the box table fits.
-    if (!(o.prim_cost_scale > 0) && o.free_media_order == 0) {
-        for (double scale : {1.0, 0.85, 0.7, 0.55, 0.4}) {
-            o.prim_cost_scale = scale;
-            rtk_optimize_info local;
-            const int rc = optimize_once(scene, &o, out_scene, &local);
-            if (rc != RTK_OK) return rc;
+    if (o.prim_cost_scale > 0) return optimize_once(scene, &o, out_scene, info);
+    const size_t budget = size_t(160) * 1024 - 2048;  // the kernel's own LDS words
+    static const double kScales[] = {1.5, 1.4, 1.2, 1.0, 0.85, 0.7, 0.55, 0.4};
+    const int n_scales = int(sizeof kScales / sizeof kScales[0]);
+    for (int k = scene->n_quads == 0 ? 0 : 3; k < n_scales; k++) {
+        o.prim_cost_scale = kScales[k];
+        rtk_optimize_info local;
+        const int rc = optimize_once(scene, &o, out_scene, &local);
+        if (rc != RTK_OK) return rc;
+        bool accept = k + 1 == n_scales || compact_program_bytes(**out_scene) <= budget;
+        if (!accept && kScales[k] <= 1.0) {
             size_t n_slots = 0, n_boxes = 0;
-            if (local.has_media) slot_program_counts(**out_scene, n_slots, n_boxes);
-            const size_t budget = size_t(160) * 1024 - 4096;  // the kernel's own LDS words and a small material table
+            slot_program_counts(**out_scene, n_slots, n_boxes);
             const size_t whole = n_slots * 64 + size_t(scene->n_materials) * 48;
-            const size_t boxes_only = n_boxes * 56 + n_slots / 2 + n_slots / 4 + 64;
-            if (!local.has_media || whole <= budget || boxes_only <= budget || scale == 0.4) {
-                if (info) *info = local;
-                return RTK_OK;
-            }
-            rtk_scene_optimized_free(*out_scene);
-            *out_scene = nullptr;
+            const size_t boxes_only = n_boxes * 56 + n_slots / 2 + n_slots / 4 + 64 + 2048;  // + a small material table
+            accept = whole <= budget || boxes_only <= budget;
         }
+        if (accept) {
+            if (info) *info = local;
+            return RTK_OK;
+        }
+        rtk_scene_optimized_free(*out_scene);
+        *out_scene = nullptr;
     }
-    return optimize_once(scene, &o, out_scene, info);
+    return RTK_ERR_INVALID;  // not reached: the last scale is always accepted
 }
 
 }  // extern "C"

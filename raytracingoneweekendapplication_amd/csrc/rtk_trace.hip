@@ -1345,8 +1345,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
 #ifndef RTK_AB_NO_TIE
 #define RTK_AB_NO_TIE 0   // tools/ab: what the tie rule costs
 #endif
-    constexpr bool TIE = !RTK_AB_NO_TIE && sizeof(real) == 8 &&
-                         ((FEAT & (F_FMA_BOX | F_F32_BOX)) != 0 || (FEAT & ~uint32_t(F_MATTE)) == kFeatQuadBox || (FEAT & ~uint32_t(F_LDS_BOXES)) == kFeatAll);
+    constexpr bool TIE = !RTK_AB_NO_TIE && sizeof(real) == 8 && ((FEAT & (F_FMA_BOX | F_F32_BOX)) != 0 || (FEAT & ~uint32_t(F_MATTE)) == kFeatQuadBox);
     const TieCtx<TIE, decltype(kind_of)> tie{TIE ? (MIXED ? sc.tie_rank : sc.tie_rank_slot) : nullptr, kind_of};
     // The hand-out order of the tiles (learned from the previous frame) is staged behind the program when the host
     // found room for it (tmap.order_in_lds): a lookup per work item from LDS instead of a cold global load.

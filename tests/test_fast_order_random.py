@@ -159,21 +159,21 @@ def random_fog_scene(seed):
 @pytest.mark.parametrize("seed", range(24))
 def test_random_fog_scenes_render_identically_in_the_fast_order(rt, orc, seed):
     """constant_medium::hit draws inside hit() (constant_medium.h:40) and runs only when the bvh_nodes above it let the ray
-    through with the interval as it stands at that moment: the optimiser keeps media and the groups above them as the
-    reference has them and re-groups the rest, so the oracle's image of its output must still be the reference order's, bit
-    for bit, draws and medium tests included.  With free_media_order the pass says the image may differ."""
+    through with the interval as it stands at that moment: the optimiser keeps every medium's position in the reference's
+    visiting order and re-groups the runs of objects in between, so the oracle's image of its output must still be the
+    reference order's, bit for bit, draws included.  With free_media_order the pass says the image may differ."""
     scene = random_fog_scene(4000 + seed)
     cam = look_at_camera(rt)
     ref, ref8, rc = orc.render(scene.desc_ptr, cam, 7, 4)
     assert rc["medium_tests"] > 0
     for eye in (cam.center, None):
         fast = rt.FastOrderScene(scene, eye)
-        assert fast.exact and fast.info["has_media"] and fast.info["n_kept_nodes"] >= 1
+        assert fast.exact and fast.info["has_media"] and fast.info["n_ordered_items"] >= 1
         got, got8, gc = orc.render(fast.desc_ptr, cam, 7, 4)
         assert np.array_equal(got, ref) and np.array_equal(got8, ref8), f"seed {seed}: max diff {np.abs(got - ref).max()}"
-        for k in ("segments", "surface_hits", "rng_draws", "medium_tests"):
+        for k in ("segments", "surface_hits", "rng_draws"):
             assert gc[k] == rc[k], k
     free = rt.FastOrderScene(scene, cam.center, free_media_order=True)
-    assert not free.exact and free.info["n_kept_nodes"] == 0
+    assert not free.exact and free.info["n_ordered_items"] == 0
     got, _, gc = orc.render(free.desc_ptr, cam, 7, 4)
     assert gc["samples"] == rc["samples"] and abs(got.mean() - ref.mean()) < 0.1 * ref.mean() + 1e-3

@@ -414,87 +414,153 @@ static double scene_extent(const rtk_scene_desc& sc, double eye_extent) {
 // boxes exactly as in build_mixed_program (rounded outward, grown by 2^-19 of the extent; same error budget -- under an
 // instance transform the kernel applies it to the object-space ray and sends a ray whose object-space origin leaves
 // [-extent, extent]^3 through the exact test), every primitive in f64, 16-byte units.
+// One record of the COMPACT layout for op i (kind = its kind with moving spheres told apart) at `dst`; links (a box's or
+// a MED_MID's `aux`) are translated through `unit_of_link`.
+static void write_compact_record(const rtk_scene_desc& sc, const Program& prog, size_t i, uint32_t kind, Unit16* dst, double margin,
+                                 const std::vector<uint32_t>& unit_of_link) {
+    const Op& op = prog.ops[i];
+    const uint32_t payload = op.kind_payload >> 4;
+    MixedHead* head = reinterpret_cast<MixedHead*>(dst);
+    double* more = reinterpret_cast<double*>(dst) + 4;  // payload element 3 onwards (byte 32)
+    head->kind_payload = make_op(kind, payload);
+    head->aux = op.aux;
+    auto with_material = [&](int32_t material) { head->aux = (op.aux & 255u) | (uint32_t(material) << 8); };
+    switch (kind) {
+        case OP_BOX: {
+            const rtk_aabb& b = sc.bvh_boxes[payload];
+            const double m = box_margin(b, margin);
+            head->f[0] = round_down(b.xmin - m); head->f[1] = round_up(b.xmax + m);
+            head->f[2] = round_down(b.ymin - m); head->f[3] = round_up(b.ymax + m);
+            head->f[4] = round_down(b.zmin - m); head->f[5] = round_up(b.zmax + m);
+            head->aux = unit_of_link[op.aux];
+            break;
+        }
+        case OP_SPHERE:
+        case OP_SPHERE_MOVING: {
+            const rtk_sphere& s = sc.spheres[payload];
+            head->d[0] = s.center0.x; head->d[1] = s.center0.y; head->d[2] = s.center0.z;
+            more[0] = s.radius;
+            more[1] = 1.0 / s.radius;  // the factor of `(p - center) / radius` (vec3.h:91-93), once instead of per hit
+            if (kind == OP_SPHERE_MOVING) { more[2] = s.center_dir.x; more[3] = s.center_dir.y; more[4] = s.center_dir.z; }
+            with_material(s.material);
+            break;
+        }
+        case OP_QUAD: {
+            const rtk_quad& q = sc.quads[payload];
+            const double vals[16] = {q.normal.x, q.normal.y, q.normal.z, q.D, q.Q.x, q.Q.y, q.Q.z, q.w.x, q.w.y, q.w.z,
+                                     q.v.x, q.v.y, q.v.z, q.u.x, q.u.y, q.u.z};
+            for (int e = 0; e < 3; e++) head->d[e] = vals[e];
+            for (int e = 3; e < 16; e++) more[e - 3] = vals[e];
+            with_material(q.material);
+            break;
+        }
+        case OP_TRI: {
+            const rtk_triangle& t = sc.triangles[payload];
+            // v0v1 = p1 - p0, v0v2 = p2 - p0 (triangle.h:67-68) in double
+            const double vals[9] = {t.p2.x - t.p0.x, t.p2.y - t.p0.y, t.p2.z - t.p0.z, t.p1.x - t.p0.x, t.p1.y - t.p0.y, t.p1.z - t.p0.z,
+                                    t.p0.x, t.p0.y, t.p0.z};
+            for (int e = 0; e < 3; e++) head->d[e] = vals[e];
+            for (int e = 3; e < 9; e++) more[e - 3] = vals[e];
+            with_material(t.material);
+            break;
+        }
+        case OP_MED_MID: head->aux = unit_of_link[op.aux]; break;
+        case OP_MED_END:
+            head->d[0] = sc.media[payload].neg_inv_density;
+            with_material(sc.media[payload].material);
+            break;
+        case OP_MED_SPHERE: {
+            const rtk_sphere& s = sc.spheres[prog.extra[i]];
+            head->d[0] = s.center0.x; head->d[1] = s.center0.y; head->d[2] = s.center0.z;
+            more[0] = s.radius;
+            more[1] = sc.media[payload].neg_inv_density;
+            with_material(sc.media[payload].material);
+            break;
+        }
+        default: break;
+    }
+}
+
+static uint32_t compact_kind_of(const rtk_scene_desc& sc, const Op& op) {
+    uint32_t kind = op.kind_payload & 15u;
+    if (kind == OP_SPHERE) {
+        const rtk_sphere& s = sc.spheres[op.kind_payload >> 4];
+        if (s.center_dir.x != 0 || s.center_dir.y != 0 || s.center_dir.z != 0) kind = OP_SPHERE_MOVING;
+    }
+    return kind;
+}
+
 static void build_compact_program(const rtk_scene_desc& sc, const Program& prog, double eye_extent, std::vector<Unit16>& units, std::vector<uint32_t>& rank_of_unit,
                                   float& extent_out) {
-    auto kind_of = [&](const Op& op) -> uint32_t {
-        uint32_t kind = op.kind_payload & 15u;
-        if (kind == OP_SPHERE) {
-            const rtk_sphere& s = sc.spheres[op.kind_payload >> 4];
-            if (s.center_dir.x != 0 || s.center_dir.y != 0 || s.center_dir.z != 0) kind = OP_SPHERE_MOVING;
-        }
-        return kind;
-    };
     std::vector<uint32_t> unit_of_op(prog.ops.size() + 1, 0);
-    for (size_t i = 0; i < prog.ops.size(); i++) unit_of_op[i + 1] = unit_of_op[i] + uint32_t(compact_units(kind_of(prog.ops[i])));
+    for (size_t i = 0; i < prog.ops.size(); i++) unit_of_op[i + 1] = unit_of_op[i] + uint32_t(compact_units(compact_kind_of(sc, prog.ops[i])));
     const double extent = double(round_up(scene_extent(sc, eye_extent) * 1.0000001));
     const double margin = std::ldexp(extent, -19);
     units.assign(unit_of_op.back(), Unit16{{0u, 0u, 0u, 0u}});
     rank_of_unit.assign(unit_of_op.back(), 0u);
     for (size_t i = 0; i < prog.ops.size(); i++) {
-        const Op& op = prog.ops[i];
-        const uint32_t kind = kind_of(op), payload = op.kind_payload >> 4;
-        MixedHead* head = reinterpret_cast<MixedHead*>(&units[unit_of_op[i]]);
-        double* more = reinterpret_cast<double*>(&units[unit_of_op[i]]) + 4;  // payload element 3 onwards (byte 32)
-        head->kind_payload = make_op(kind, payload);
-        head->aux = op.aux;
+        write_compact_record(sc, prog, i, compact_kind_of(sc, prog.ops[i]), &units[unit_of_op[i]], margin, unit_of_op);
         rank_of_unit[unit_of_op[i]] = prog.ranks[i];
-        auto with_material = [&](int32_t material) { head->aux = (op.aux & 255u) | (uint32_t(material) << 8); };
-        switch (kind) {
-            case OP_BOX: {
-                const rtk_aabb& b = sc.bvh_boxes[payload];
-                const double m = box_margin(b, margin);
-                head->f[0] = round_down(b.xmin - m); head->f[1] = round_up(b.xmax + m);
-                head->f[2] = round_down(b.ymin - m); head->f[3] = round_up(b.ymax + m);
-                head->f[4] = round_down(b.zmin - m); head->f[5] = round_up(b.zmax + m);
-                head->aux = unit_of_op[op.aux];
-                break;
-            }
-            case OP_SPHERE:
-            case OP_SPHERE_MOVING: {
-                const rtk_sphere& s = sc.spheres[payload];
-                head->d[0] = s.center0.x; head->d[1] = s.center0.y; head->d[2] = s.center0.z;
-                more[0] = s.radius;
-                more[1] = 1.0 / s.radius;  // the factor of `(p - center) / radius` (vec3.h:91-93), once instead of per hit
-                if (kind == OP_SPHERE_MOVING) { more[2] = s.center_dir.x; more[3] = s.center_dir.y; more[4] = s.center_dir.z; }
-                with_material(s.material);
-                break;
-            }
-            case OP_QUAD: {
-                const rtk_quad& q = sc.quads[payload];
-                const double vals[16] = {q.normal.x, q.normal.y, q.normal.z, q.D, q.Q.x, q.Q.y, q.Q.z, q.w.x, q.w.y, q.w.z,
-                                         q.v.x, q.v.y, q.v.z, q.u.x, q.u.y, q.u.z};
-                for (int e = 0; e < 3; e++) head->d[e] = vals[e];
-                for (int e = 3; e < 16; e++) more[e - 3] = vals[e];
-                with_material(q.material);
-                break;
-            }
-            case OP_TRI: {
-                const rtk_triangle& t = sc.triangles[payload];
-                // v0v1 = p1 - p0, v0v2 = p2 - p0 (triangle.h:67-68) in double
-                const double vals[9] = {t.p2.x - t.p0.x, t.p2.y - t.p0.y, t.p2.z - t.p0.z, t.p1.x - t.p0.x, t.p1.y - t.p0.y, t.p1.z - t.p0.z,
-                                        t.p0.x, t.p0.y, t.p0.z};
-                for (int e = 0; e < 3; e++) head->d[e] = vals[e];
-                for (int e = 3; e < 9; e++) more[e - 3] = vals[e];
-                with_material(t.material);
-                break;
-            }
-            case OP_MED_MID: head->aux = unit_of_op[op.aux]; break;
-            case OP_MED_END:
-                head->d[0] = sc.media[payload].neg_inv_density;
-                with_material(sc.media[payload].material);
-                break;
-            case OP_MED_SPHERE: {
-                const rtk_sphere& s = sc.spheres[prog.extra[i]];
-                head->d[0] = s.center0.x; head->d[1] = s.center0.y; head->d[2] = s.center0.z;
-                more[0] = s.radius;
-                more[1] = sc.media[payload].neg_inv_density;
-                with_material(sc.media[payload].material);
-                break;
-            }
-            default: break;
-        }
     }
     extent_out = float(extent);
+}
+
+// The same program in two parts, for COMPACT programs that do not fit one CU's LDS (rtk_device_layout.h, SceneView::
+// program_hot): quads and triangles -- the bulky records, tested a few times per sample -- go to `cold` in program order;
+// `hot` is the program without them, each run of consecutive quads (or triangles) replaced by ONE two-unit record {kind,
+// count; aux = first unit of the run in `cold`}.  A run ends where the kind changes, at 255 primitives, and in front of any
+// record some box or medium links to (so that every link target is the start of a record of the hot program).
+// rank_of_id[unit of a hot record, or hot.size() + unit of a cold one] = the primitive's reference rank.
+static void build_hot_cold_program(const rtk_scene_desc& sc, const Program& prog, double eye_extent, std::vector<Unit16>& hot, std::vector<Unit16>& cold,
+                                   std::vector<uint32_t>& rank_of_id) {
+    const size_t n = prog.ops.size();
+    std::vector<uint32_t> kind(n);
+    std::vector<char> is_target(n + 1, 0);
+    for (size_t i = 0; i < n; i++) {
+        kind[i] = compact_kind_of(sc, prog.ops[i]);
+        if (kind[i] == OP_BOX || kind[i] == OP_MED_MID) is_target[prog.ops[i].aux] = 1;
+    }
+    auto is_cold = [&](size_t i) { return kind[i] == OP_QUAD || kind[i] == OP_TRI; };
+    std::vector<uint32_t> hot_unit(n + 1, 0), cold_unit(n, 0), run_len(n, 0);
+    uint32_t n_hot = 0, n_cold = 0;
+    for (size_t i = 0; i < n;) {
+        if (!is_cold(i)) {
+            hot_unit[i] = n_hot;
+            n_hot += uint32_t(compact_units(kind[i]));
+            i++;
+            continue;
+        }
+        size_t j = i;
+        while (j < n && is_cold(j) && kind[j] == kind[i] && (j == i || !is_target[j]) && j - i < 255) {
+            hot_unit[j] = n_hot;  // (only the run's first primitive can be a link target)
+            cold_unit[j] = n_cold;
+            n_cold += uint32_t(compact_units(kind[j]));
+            j++;
+        }
+        run_len[i] = uint32_t(j - i);
+        n_hot += 2;
+        i = j;
+    }
+    hot_unit[n] = n_hot;
+    const double extent = double(round_up(scene_extent(sc, eye_extent) * 1.0000001));
+    const double margin = std::ldexp(extent, -19);
+    hot.assign(n_hot, Unit16{{0u, 0u, 0u, 0u}});
+    cold.assign(std::max<uint32_t>(n_cold, 1u), Unit16{{0u, 0u, 0u, 0u}});
+    rank_of_id.assign(size_t(n_hot) + cold.size(), 0u);
+    for (size_t i = 0; i < n; i++) {
+        if (!is_cold(i)) {
+            write_compact_record(sc, prog, i, kind[i], &hot[hot_unit[i]], margin, hot_unit);
+            rank_of_id[hot_unit[i]] = prog.ranks[i];
+            continue;
+        }
+        if (run_len[i] > 0) {
+            MixedHead* run = reinterpret_cast<MixedHead*>(&hot[hot_unit[i]]);
+            run->kind_payload = make_op(kind[i], run_len[i]);
+            run->aux = cold_unit[i];
+        }
+        write_compact_record(sc, prog, i, kind[i], &cold[cold_unit[i]], margin, hot_unit);
+        rank_of_id[size_t(n_hot) + cold_unit[i]] = prog.ranks[i];
+    }
 }
 
 template <typename real>
@@ -726,6 +792,10 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
     }
     out.view.program_compact = nullptr;
     out.view.n_units16 = 0;
+    out.view.program_hot = nullptr;
+    out.view.program_cold = nullptr;
+    out.view.n_hot_units = out.view.n_cold_units = 0;
+    out.view.tie_rank_hot = nullptr;
     out.view.tie_rank = nullptr;
     out.view.tie_rank_slot = nullptr;
     if (fast_order) {  // reference ranks of the primitive records, for exact ties (see SceneView::tie_rank)
@@ -752,6 +822,19 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
             if ((rc = out.upload(units, &out.view.program_compact)) != RTK_OK) return rc;
             if ((rc = out.upload(ranks, &out.view.tie_rank)) != RTK_OK) return rc;
             out.view.n_units16 = int32_t(units.size());
+            if (units.size() * sizeof(Unit16) + mats.size() * sizeof(MaterialRec<real>) > size_t(kLdsBytesPerCU)) {
+                std::vector<Unit16> hot, cold;
+                std::vector<uint32_t> ranks_by_id;
+                build_hot_cold_program(sc, prog, eye_extent, hot, cold, ranks_by_id);
+                if (getenv("RTK_DEBUG")) fprintf(stderr, "[rtk] COMPACT program %zu B; hot part %zu B, cold part %zu B\n", units.size() * 16, hot.size() * 16, cold.size() * 16);
+                if (hot.size() * sizeof(Unit16) + mats.size() * sizeof(MaterialRec<real>) + 64 <= size_t(kLdsBytesPerCU) && hot.size() < (size_t(1) << 24)) {
+                    if ((rc = out.upload(hot, &out.view.program_hot)) != RTK_OK) return rc;
+                    if ((rc = out.upload(cold, &out.view.program_cold)) != RTK_OK) return rc;
+                    if ((rc = out.upload(ranks_by_id, &out.view.tie_rank_hot)) != RTK_OK) return rc;
+                    out.view.n_hot_units = int32_t(hot.size());
+                    out.view.n_cold_units = int32_t(cold.size());
+                }
+            }
         }
     }
     return RTK_OK;
@@ -1295,3 +1378,24 @@ const char* rtk_kernel_name(rtk_ctx* ctx, int real_mode, int variant) {
 }
 
 }  // extern "C"
+
+namespace rtk {
+
+// What the hot part of `scene`'s COMPACT program takes in LDS, materials included (build_hot_cold_program; exact: the
+// program is compiled).  For rtk_scene_optimize's choice of the primitive cost (rtk_optimize.cpp); 0 when the
+// description does not compile.
+size_t hot_program_lds_bytes(const rtk_scene_desc* scene) {
+    if (!scene) return 0;
+    try {
+        Program prog;
+        if (compile_scene(scene, prog) != RTK_OK) return 0;
+        std::vector<Unit16> hot, cold;
+        std::vector<uint32_t> ranks;
+        build_hot_cold_program(*scene, prog, 0.0, hot, cold, ranks);
+        return hot.size() * sizeof(Unit16) + size_t(scene->n_materials) * sizeof(MaterialRec<double>);
+    } catch (const std::bad_alloc&) {
+        return 0;
+    }
+}
+
+}  // namespace rtk

@@ -231,6 +231,14 @@ struct SceneView {  // device pointers, passed to the kernel by value
     // the reference order) -- same `extent` rule, applied to the object-space origin under instance transforms
     const Unit16* program_compact;
     int32_t n_units16;
+    // ... and, for COMPACT programs too large for LDS, the same program in two parts (F_LDS_BOXES | F_F32_BOX kernels): the
+    // hot part -- staged in LDS -- holds every record except quads and triangles, with one two-unit record {kind, count;
+    // aux = first unit in program_cold} per run of them; program_cold holds those primitives' usual records.  A hit on a
+    // cold primitive is named n_hot_units + its unit; tie_rank_hot is indexed the same way.  Null when not built.
+    const Unit16* program_hot;
+    const Unit16* program_cold;
+    int32_t n_hot_units, n_cold_units;
+    const uint32_t* tie_rank_hot;
     // Fast-order uploads: rank of the primitive record at pc in the REFERENCE's visiting order (rtk_node.c), indexed by the
     // pc of the f32-box program (MIXED units or COMPACT units) resp. of the slot program; 0 = unknown.  Only read when two
     // primitives are hit at exactly the same distance, to resolve the tie the way the reference's left-to-right

@@ -703,6 +703,10 @@ struct Optimizer {
 
 }  // namespace
 
+namespace rtk {
+size_t hot_program_lds_bytes(const rtk_scene_desc* scene);  // rtk_api.cpp
+}
+
 extern "C" {
 
 static int optimize_once(const rtk_scene_desc* scene, const rtk_optimize_opts* opts_in, rtk_scene_desc** out_scene, rtk_optimize_info* info) {
@@ -863,9 +867,10 @@ static void slot_program_counts(const rtk_scene_desc& d, size_t& n_slots, size_t
 //    long as its COMPACT program still fits one CU's LDS: a program that has to leave LDS loses far more than the better
 //    hierarchy gains (C4 at 1.6x: 175 ms), so the scale steps down (1.4, 1.2, 1.0) until it fits.  Scenes with quads start
 //    at 1.0 (the Cornell box is flat between 1.0 and 1.5 and worse in between);
-//  * a program that fits LDS in neither form (C5: 2 400 quads) runs from memory with its box records in LDS, if those
-//    fit: primitive tests are priced DOWN step by step (fewer, larger leaves: fewer boxes) until they do (C5: 3 100
-//    boxes at 1.0 = 173 KB; about 2 500 at 0.7 fit, 1 081 Msamples/s against 990 with the boxes in memory).
+//  * a program too large for that (C5: 2 400 quads of 144 bytes) keeps its HOT part there -- boxes, spheres, everything
+//    but the quads and triangles, which stay in memory (SceneView::program_hot) -- and primitive tests are priced DOWN
+//    step by step (fewer, larger leaves: fewer boxes) until that part fits; failing that, until at least the box
+//    records of the slot program do (the boxes-in-LDS kernels).
 // An explicit scale is honoured as given.
 int rtk_scene_optimize(const rtk_scene_desc* scene, const rtk_optimize_opts* opts_in, rtk_scene_desc** out_scene, rtk_optimize_info* info) {
     if (!scene || !out_scene) return RTK_ERR_INVALID;
@@ -874,29 +879,53 @@ int rtk_scene_optimize(const rtk_scene_desc* scene, const rtk_optimize_opts* opt
     if (opts_in) o = *opts_in;
     if (o.prim_cost_scale > 0) return optimize_once(scene, &o, out_scene, info);
     const size_t budget = size_t(160) * 1024 - 2048;  // the kernel's own LDS words
-    static const double kScales[] = {1.5, 1.4, 1.2, 1.0, 0.85, 0.7, 0.55, 0.4};
+    static const double kScales[] = {1.5, 1.4, 1.2, 1.0, 0.85, 0.7, 0.6, 0.5, 0.4};
     const int n_scales = int(sizeof kScales / sizeof kScales[0]);
+    const bool full_feature = scene->n_media > 0 || scene->n_translates > 0 || scene->n_rotates > 0;  // only those kernels have the hot/cold form
+    rtk_scene_desc* fallback = nullptr;  // the first hierarchy whose slot program at least keeps its boxes in LDS
+    rtk_optimize_info fallback_info;
     for (int k = scene->n_quads == 0 ? 0 : 3; k < n_scales; k++) {
         o.prim_cost_scale = kScales[k];
         rtk_optimize_info local;
-        const int rc = optimize_once(scene, &o, out_scene, &local);
-        if (rc != RTK_OK) return rc;
-        bool accept = k + 1 == n_scales || compact_program_bytes(**out_scene) <= budget;
-        if (!accept && kScales[k] <= 1.0) {
-            size_t n_slots = 0, n_boxes = 0;
-            slot_program_counts(**out_scene, n_slots, n_boxes);
-            const size_t whole = n_slots * 64 + size_t(scene->n_materials) * 48;
-            const size_t boxes_only = n_boxes * 56 + n_slots / 2 + n_slots / 4 + 64 + 2048;  // + a small material table
-            accept = whole <= budget || boxes_only <= budget;
+        rtk_scene_desc* candidate = nullptr;
+        const int rc = optimize_once(scene, &o, &candidate, &local);
+        if (rc != RTK_OK) {
+            if (fallback) rtk_scene_optimized_free(fallback);
+            return rc;
+        }
+        bool accept = compact_program_bytes(*candidate) <= budget;
+        if (!accept && kScales[k] <= 1.0 && full_feature) {
+            // the hot part (rtk_api.cpp compiles the program: exact), and the Perlin tables behind it: book-2's noise sphere
+            // costs 4 % of the frame when perlin::turb gathers from memory instead
+            const size_t hot = rtk::hot_program_lds_bytes(candidate);
+            accept = hot > 0 && hot + size_t(scene->n_perlins) * 9216 <= budget;
         }
         if (accept) {
+            if (fallback) rtk_scene_optimized_free(fallback);
+            *out_scene = candidate;
             if (info) *info = local;
             return RTK_OK;
         }
-        rtk_scene_optimized_free(*out_scene);
-        *out_scene = nullptr;
+        bool keep = false;
+        if (!fallback && kScales[k] <= 1.0) {
+            size_t n_slots = 0, n_boxes = 0;
+            slot_program_counts(*candidate, n_slots, n_boxes);
+            const size_t whole = n_slots * 64 + size_t(scene->n_materials) * 48;
+            const size_t boxes_only = n_boxes * 56 + n_slots / 2 + n_slots / 4 + 64 + 2048;  // + a small material table
+            keep = whole <= budget || boxes_only <= budget || k + 1 == n_scales;
+        }
+        if (keep || (!fallback && k + 1 == n_scales)) {
+            fallback = candidate;
+            fallback_info = local;
+        } else {
+            rtk_scene_optimized_free(candidate);
+        }
+        if (fallback && !full_feature) break;  // no hot/cold form to look for further down
     }
-    return RTK_ERR_INVALID;  // not reached: the last scale is always accepted
+    if (!fallback) return RTK_ERR_INVALID;  // not reached: the last scale is always kept
+    *out_scene = fallback;
+    if (info) *info = fallback_info;
+    return RTK_OK;
 }
 
 }  // extern "C"

@@ -978,8 +978,9 @@ RTK_DEV void begin_sample(Lane<real>& L, const CameraRec<real>& cam, int i, int 
 // The traversal program ran to OP_END: the body of ray_color after world.hit
 // (Camera.txt:211-237), iteratively (radiance = sum of throughput * emission).
 // Returns true when the sample's path has ended.
+// `hit_rec` = the record of the closest hit (program + L.best_pc; anything when there is none).
 template <typename real, uint32_t FEAT, bool COUNT, typename ProgT>
-RTK_DEV bool shade(Lane<real>& L, const ProgT* __restrict__ prog, const SceneView<real>& sc, const MaterialRec<real>* __restrict__ mats,
+RTK_DEV bool shade(Lane<real>& L, const ProgT* __restrict__ hit_rec, const SceneView<real>& sc, const MaterialRec<real>* __restrict__ mats,
                    const CameraRec<real>& cam, Counters<COUNT>& cnt) {
     if (L.best_pc == kNoHit) {  // Camera.txt:211-213
         L.radiance = L.radiance + L.throughput * ld3(cam.background);
@@ -987,8 +988,8 @@ RTK_DEV bool shade(Lane<real>& L, const ProgT* __restrict__ prog, const SceneVie
     }
     cnt.inc(C_SURFACE);
     Surface<real> sf;
-    if constexpr (std::is_same_v<ProgT, MixedHead>) make_surface_mixed(prog, L.best_pc, L.best_t, L.ro, L.rd, L.tm, sf);  // lean MIXED program
-    else make_surface<real, FEAT>(prog, sc, mats, L.best_pc, L.best_t, L.ro, L.rd, L.tm, sf);                             // slot or COMPACT program
+    if constexpr (std::is_same_v<ProgT, MixedHead>) make_surface_mixed(hit_rec, 0u, L.best_t, L.ro, L.rd, L.tm, sf);  // lean MIXED program
+    else make_surface<real, FEAT>(hit_rec, sc, mats, 0u, L.best_t, L.ro, L.rd, L.tm, sf);                             // slot or COMPACT program
     const MaterialRec<real>& m = mats[sf.material];
     const V3<real> rd = L.rd;
 
@@ -1226,24 +1227,33 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
 #define RTK_DEV_MASK_OFF 0u   // register-pressure experiments (tools/kernel_resources.py): feature bits compiled out of every kernel
 #endif
     constexpr uint32_t FEAT = FEAT_ALL & ~uint32_t(F_LDS_BOXES) & ~uint32_t(RTK_DEV_MASK_OFF);
-    constexpr bool SPLIT = (FEAT_ALL & F_LDS_BOXES) != 0;  // boxes, kinds and the rank table in LDS; everything else of the program in HBM/L2
-    static_assert(!SPLIT || !IN_LDS, "F_LDS_BOXES: for programs that do not fit LDS");
+    constexpr bool LDS_PART = (FEAT_ALL & F_LDS_BOXES) != 0;  // a program larger than LDS, part of it staged there
+    static_assert(!LDS_PART || !IN_LDS, "F_LDS_BOXES: for programs that do not fit LDS");
     constexpr bool MIXED = (FEAT & F_F32_BOX) != 0;  // f32 culling boxes + exact primitives (f64 kernels, fast order): ...
     // ... the MIXED program of sphere-only scenes (32-byte units) or, for every other family, the COMPACT program (16-byte units)
     constexpr bool COMPACT = MIXED && (FEAT & ~uint32_t(F_F32_BOX | F_MATTE)) != kFeatLean;
     static_assert(!MIXED || sizeof(real) == 8, "F_F32_BOX: f64 kernels only");
-    static_assert(!SPLIT || !MIXED, "F_LDS_BOXES: slot programs only (a COMPACT program split between LDS and memory lost to the slot program: C4 175 vs 95 ms)");
+    // ... which part depends on the layout.  Slot program (SPLIT): the box slots, the kind nibbles and a rank table.  COMPACT
+    // program (COLD): the whole "hot" program -- f32 culling boxes, spheres, every rare record -- in which each run of quads
+    // or triangles is ONE two-unit record {kind, count, first unit in the cold array}; the quads and triangles themselves
+    // ("cold": 144 / 80 bytes each, tested a few times per sample) stay in memory (SceneView::program_cold).
+    constexpr bool SPLIT = LDS_PART && !COMPACT;
+    constexpr bool COLD = LDS_PART && COMPACT;
+    static_assert(!LDS_PART || !MIXED || COMPACT, "F_LDS_BOXES with f32 boxes: the COMPACT program");
     constexpr bool XF = (FEAT & F_XFORM) != 0;
     using ProgRec = std::conditional_t<COMPACT, Unit16, std::conditional_t<MIXED, MixedHead, Slot<real>>>;  // what pc counts
     using CurRec = std::conditional_t<MIXED, MixedHead, Slot<real>>;                                      // the record head a step holds in registers
     constexpr uint32_t kBoxUnits = COMPACT ? 2u : 1u, kSphereUnits = COMPACT ? 3u : (MIXED ? 2u : 1u), kQuadUnits = COMPACT ? 9u : 3u, kTriUnits = COMPACT ? 5u : 2u;
     const ProgRec* prog;
-    if constexpr (COMPACT) prog = sc.program_compact;
+    if constexpr (COLD) prog = sc.program_hot;
+    else if constexpr (COMPACT) prog = sc.program_compact;
     else if constexpr (MIXED) prog = sc.program_mixed;
     else prog = sc.program;
-    const int n_records = COMPACT ? sc.n_units16 : (MIXED ? sc.n_units : sc.n_slots);  // units of sizeof(ProgRec)
+    const int n_records = COLD ? sc.n_hot_units : (COMPACT ? sc.n_units16 : (MIXED ? sc.n_units : sc.n_slots));  // units of sizeof(ProgRec)
+    [[maybe_unused]] const Unit16* cold = nullptr;
+    if constexpr (COLD) cold = sc.program_cold;
     const MaterialRec<real>* mats = sc.materials;
-    if constexpr (IN_LDS) {  // program, then the material table, both as 16-byte words
+    if constexpr (IN_LDS || COLD) {  // program (COLD: its hot part), then the material table, both as 16-byte words
         const int n_prog16 = n_records * int(sizeof(ProgRec) / 16);
         const int n_mat16 = sc.n_materials * int(sizeof(MaterialRec<real>) / 16);
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(prog);
@@ -1251,6 +1261,15 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
         uint4* dst = reinterpret_cast<uint4*>(lds_program);
         for (int k = threadIdx.x; k < n_prog16; k += blockDim.x) dst[k] = src[k];
         for (int k = threadIdx.x; k < n_mat16; k += blockDim.x) dst[n_prog16 + k] = msrc[k];
+        if constexpr (COLD && (FEAT & F_TEXTURE) != 0) {  // the Perlin tables as well when the launcher found room
+            if (tmap.perlin_lds_offset > 0) {
+                const int n16 = sc.n_perlins * int(sizeof(PerlinRec<real>) / 16);
+                const uint4* __restrict__ psrc = reinterpret_cast<const uint4*>(sc.perlins);
+                uint4* pdst = reinterpret_cast<uint4*>(lds_program + tmap.perlin_lds_offset);
+                for (int k = threadIdx.x; k < n16; k += blockDim.x) pdst[k] = psrc[k];
+                sc.perlins = reinterpret_cast<const PerlinRec<real>*>(lds_program + tmap.perlin_lds_offset);
+            }
+        }
         __syncthreads();
         prog = reinterpret_cast<const ProgRec*>(lds_program);
         mats = reinterpret_cast<const MaterialRec<real>*>(lds_program + size_t(n_prog16) * 16);
@@ -1297,14 +1316,16 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
         lds_rank = rdst;
     }
     // the head of the record that starts at pc, as a step holds it in registers
+    // (COLD: a lane inside a run of cold primitives keeps its position in the run in the top byte of its pc)
+    constexpr uint32_t kPcMask = COLD ? 0x00FFFFFFu : 0xFFFFFFFFu;
     auto head_at = [&](uint32_t pc) -> CurRec {
-        if constexpr (COMPACT) return *reinterpret_cast<const MixedHead*>(prog + pc);
+        if constexpr (COMPACT) return *reinterpret_cast<const MixedHead*>(prog + (pc & kPcMask));
         else return prog[pc];
     };
     // kind of the record that starts at pc; the box record at pc (SPLIT: from the LDS copies)
     auto kind_of = [&](uint32_t pc) -> uint32_t {
         if constexpr (SPLIT) return (lds_kinds[pc >> 3] >> ((pc & 7u) * 4u)) & 15u;
-        else if constexpr (COMPACT) return prog[pc + 1].w[2] & 15u;
+        else if constexpr (COMPACT) return prog[(pc & kPcMask) + 1].w[2] & 15u;
         else return prog[pc].kind_payload & 15u;
     };
     [[maybe_unused]] auto box_at = [&](uint32_t pc) -> CurRec {
@@ -1321,6 +1342,15 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             s.aux = b.aux;
             return s;
         }
+    };
+    // The record a closest hit names (L.best_pc): a pc of the program, or -- COLD -- n_records + the unit of a cold primitive.
+    auto record_of = [&](uint32_t id) -> const ProgRec* {
+        if constexpr (COLD) return id < uint32_t(n_records) ? prog + id : reinterpret_cast<const ProgRec*>(cold + (id - uint32_t(n_records)));
+        else return prog + id;
+    };
+    [[maybe_unused]] auto kind_of_hit = [&](uint32_t id) -> uint32_t {  // for the tie rule: the kind of the current winner
+        if constexpr (COLD) return id < uint32_t(n_records) ? kind_of(id) : (cold[id - uint32_t(n_records) + 1].w[2] & 15u);
+        else return kind_of(id);
     };
     // exact ties between primitives are resolved by the reference's ranks in the kernels that run re-grouped hierarchies
     // (the quad/box subset kernel serves the fast order without a flag of its own)
@@ -1346,7 +1376,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
 #define RTK_AB_NO_TIE 0   // tools/ab: what the tie rule costs
 #endif
     constexpr bool TIE = !RTK_AB_NO_TIE && sizeof(real) == 8 && ((FEAT & (F_FMA_BOX | F_F32_BOX)) != 0 || (FEAT & ~uint32_t(F_MATTE)) == kFeatQuadBox);
-    const TieCtx<TIE, decltype(kind_of)> tie{TIE ? (MIXED ? sc.tie_rank : sc.tie_rank_slot) : nullptr, kind_of};
+    const TieCtx<TIE, decltype(kind_of_hit)> tie{TIE ? (COLD ? sc.tie_rank_hot : (MIXED ? sc.tie_rank : sc.tie_rank_slot)) : nullptr, kind_of_hit};
     // The hand-out order of the tiles (learned from the previous frame) is staged behind the program when the host
     // found room for it (tmap.order_in_lds): a lookup per work item from LDS instead of a cold global load.
     const int32_t* lds_order = nullptr;
@@ -1398,6 +1428,26 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
     RTK_PROF_DECL
     int my_slot = 0, my_pix = 0, px_i = 0, px_j = 0, s_end = 0, cost_tile = -1;  // my_slot = chunk * n_tiles_local + local_tile: where the partial sum goes
 
+    // COLD: one primitive of the run the lane sits on.  The run record (hot, two units) = {kind, count | aux = first unit
+    // in the cold array}; the lane's position in the run rides in the top byte of its pc.  A hit is recorded under the id
+    // n_records + cold unit (record_of / the rank table understand it); after the last primitive the lane walks on in
+    // the hot program.
+    [[maybe_unused]] auto cold_step = [&](auto is_quad, uint32_t& k) {
+        if constexpr (COLD) {
+            constexpr bool QUAD = decltype(is_quad)::value;
+            constexpr uint32_t units = QUAD ? 9u : 5u;
+            const uint32_t hot = L.pc & kPcMask, sub = L.pc >> 24;
+            const MixedHead run = head_at(hot);
+            const uint32_t at = run.aux + sub * units;
+            L.pc = uint32_t(n_records) + at;
+            if constexpr (QUAD) hit_quad<XF, MIXED>(L, reinterpret_cast<const ProgRec*>(cold + at), 0u, cnt, tie);
+            else hit_tri<XF, MIXED>(L, reinterpret_cast<const ProgRec*>(cold + at), 0u, cnt, tie);
+            const bool last = sub + 1u >= (run.kind_payload >> 4);
+            L.pc = last ? hot + 2u : (hot | ((sub + 1u) << 24));
+            k = last ? kind_of(L.pc) : uint32_t(QUAD ? OP_QUAD : OP_TRI);
+            L.kind = k;
+        }
+    };
     // One refill round: idle lanes take the next pixels of the wave's current work item (a tile x a chunk of the
     // samples); when the item is used up the wave first pulls another one from the rank-wide counter.  A (pixel,
     // chunk) belongs to exactly one lane, which walks its samples in order.  Returns true when idle lanes remain that
@@ -1621,9 +1671,14 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                     // C4 47.8 -> 42.5 ms at 16 lanes (8: 42.8, 24: 43.6)
                     if (popcount64(__ballot(k == OP_TRI)) >= RTK_TRI_RIDE) {
                         if (k == OP_TRI) {
-                            hit_tri<XF, MIXED>(L, prog + L.pc, kTriUnits, cnt, tie);
-                            fetch();
-                            L.kind = k;
+                            if constexpr (COLD) {
+                                cold_step(std::false_type{}, k);
+                                cur = head_at(L.pc);
+                            } else {
+                                hit_tri<XF, MIXED>(L, prog + L.pc, kTriUnits, cnt, tie);
+                                fetch();
+                                L.kind = k;
+                            }
                         }
                     }
                 }
@@ -1686,9 +1741,13 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
 #endif
             do {
                 if (k == OP_QUAD) {
-                    hit_quad<XF, MIXED>(L, prog + L.pc, kQuadUnits, cnt, tie);
-                    k = kind_of(L.pc);
-                    L.kind = k;
+                    if constexpr (COLD) {
+                        cold_step(std::true_type{}, k);
+                    } else {
+                        hit_quad<XF, MIXED>(L, prog + L.pc, kQuadUnits, cnt, tie);
+                        k = kind_of(L.pc);
+                        L.kind = k;
+                    }
                 }
                 remaining = popcount64(__ballot(k == OP_QUAD));
                 RTK_PROF_MARK(5, 1, remaining)
@@ -1708,9 +1767,13 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
 #endif
             do {
                 if (k == OP_TRI) {
-                    hit_tri<XF, MIXED>(L, prog + L.pc, kTriUnits, cnt, tie);
-                    k = kind_of(L.pc);
-                    L.kind = k;
+                    if constexpr (COLD) {
+                        cold_step(std::false_type{}, k);
+                    } else {
+                        hit_tri<XF, MIXED>(L, prog + L.pc, kTriUnits, cnt, tie);
+                        k = kind_of(L.pc);
+                        L.kind = k;
+                    }
                 }
                 remaining = popcount64(__ballot(k == OP_TRI));
                 RTK_PROF_MARK(5, 1, remaining)
@@ -1727,7 +1790,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
 #endif
             if (kind == OP_END) {
                 alive = true;
-                const bool ended = L.depth <= 0 || shade<real, FEAT, COUNT>(L, prog, sc, mats, cam, cnt);
+                const bool ended = L.depth <= 0 || shade<real, FEAT, COUNT>(L, record_of(L.best_pc), sc, mats, cam, cnt);
                 if (ended) {  // pixel_color += ray_color(...) (Camera.txt:72)
                     L.sum = L.sum + L.radiance;
                     L.s += 1;
@@ -2025,7 +2088,8 @@ static size_t lds_image_bytes(const SceneView<real>& sc, uint32_t feat) {
 
 // F_LDS_BOXES kernels: the box slots, the kind nibbles (padded to 8 bytes) and the rank table.
 template <typename real>
-static size_t split_lds_bytes(const SceneView<real>& sc, uint32_t) {
+static size_t split_lds_bytes(const SceneView<real>& sc, uint32_t feat) {
+    if (is_compact(feat)) return size_t(sc.n_hot_units) * sizeof(Unit16) + size_t(sc.n_materials) * sizeof(MaterialRec<real>);  // COLD: hot program + materials
     return size_t(sc.n_cached_boxes) * sizeof(BoxRec<real>) + ((size_t(sc.n_kind_words) * 4 + 7) & ~size_t(7)) + size_t(sc.n_rank_words) * 8;
 }
 template <typename real, uint32_t FEAT, bool COUNT, bool IN_LDS>
@@ -2042,7 +2106,8 @@ static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>* c
     if constexpr ((FEAT & F_LDS_BOXES) != 0) {  // boxes-in-LDS kernels: the material table too, if it is small and there is room
         const size_t mat_bytes = size_t(sc.n_materials) * sizeof(MaterialRec<real>);
         const size_t at = (lds + 15) & ~size_t(15);
-        if (RTK_SPLIT_MATERIALS_IN_LDS && mat_bytes <= 16 * 1024 && at + mat_bytes + 64 <= size_t(kLdsBytesPerCU)) {
+        if (!is_compact(FEAT) /* (COLD kernels always stage it, right behind the hot program) */ && RTK_SPLIT_MATERIALS_IN_LDS && mat_bytes <= 16 * 1024 &&
+            at + mat_bytes + 64 <= size_t(kLdsBytesPerCU)) {
             tm.mats_lds_offset = int32_t(at);
             lds = at + mat_bytes;
         }
@@ -2110,13 +2175,21 @@ template <typename real>
 static KernelChoice choose_kernel(const SceneView<real>& sc, uint32_t features, bool count, bool allow_lds, uint32_t diag) {
     const bool mixed = use_mixed_program(sc, diag);
     bool compact = use_compact_program(sc, diag);
+    bool cold = false;
     if (compact) {
         // Only when it fits one CU's LDS.  A COMPACT program split between LDS (box heads) and memory (primitives) is slower
         // than the slot program split the same way, measured: C4 with 4 494 ops 175 ms against 95 ms, C5 714 against 838
         // Msamples/s (there the coordinates run into the thousands -- a fog boundary of radius 5000 -- and the 2^-19 x extent
         // margin exceeds a quad's own box thickness: +55 % quad tests).
         const size_t bytes = size_t(sc.n_units16) * sizeof(Unit16) + size_t(sc.n_materials) * sizeof(MaterialRec<real>);
-        if (!(allow_lds && bytes <= size_t(kLdsBytesPerCU))) compact = false;
+        if (!(allow_lds && bytes <= size_t(kLdsBytesPerCU))) {
+            // ... unless its hot part does (COLD kernels: quads and triangles stay in memory, everything else in LDS) -- full-feature family, timed kernels
+            const size_t hot = size_t(sc.n_hot_units) * sizeof(Unit16) + size_t(sc.n_materials) * sizeof(MaterialRec<real>);
+            const uint32_t scene = features & ~uint32_t(F_FMA_BOX | F_MATTE);
+            cold = allow_lds && !count && sc.program_hot != nullptr && hot + 64 <= size_t(kLdsBytesPerCU) && (diag & (1u << 21)) == 0 &&
+                   (scene & ~kFeatQuadBox) != 0 && (scene & ~kFeatMesh) != 0;
+            compact = cold;
+        }
     }
     // the matte variants pay off in f64 only (C3: f64 34.8 -> 31.9 ms, f32 26.6 -> 36.5 ms at one more wave per SIMD)
     KernelChoice k{kernel_features(sizeof(real) == 8 ? features : (features & ~uint32_t(F_MATTE)), count, mixed, compact), count, false};
@@ -2127,6 +2200,11 @@ static KernelChoice choose_kernel(const SceneView<real>& sc, uint32_t features, 
         return k;
     }
     k.in_lds = fits;
+    if (cold) {
+        k.in_lds = false;
+        k.feat |= uint32_t(F_LDS_BOXES);
+        return k;
+    }
     // a program larger than LDS whose box records are not: the boxes-in-LDS kernel (mesh and full-feature families)
     if (!fits && !(k.feat & F_F32_BOX) && sc.box_cache != nullptr && (scene == kFeatMesh || scene == kFeatAll) && (diag & (1u << 21)) == 0) k.feat |= uint32_t(F_LDS_BOXES);
     return k;
@@ -2148,6 +2226,7 @@ static hipError_t launch_feat(const KernelChoice& k, const SceneView<real>& sc, 
     }
     if constexpr (FEAT == (kFeatAll | uint32_t(F_F32_BOX))) {  // work counters on the COMPACT program (any family's scene)
         if (k.count) RTK_GO(FEAT, true, false);
+        if (k.feat & F_LDS_BOXES) RTK_GO(FEAT | uint32_t(F_LDS_BOXES), false, false);  // COLD: hot program in LDS, quads / triangles in memory
     }
     if constexpr ((FEAT & F_F32_BOX) == 0 && ((FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatMesh || (FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatAll)) {
         if (k.feat & F_LDS_BOXES) RTK_GO(FEAT | uint32_t(F_LDS_BOXES), false, false);  // (slot programs only: see choose_kernel)

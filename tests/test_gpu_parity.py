@@ -312,9 +312,17 @@ def test_config4_and_config5_full_resolution_reduced_spp_properties(rt, orc, ren
     img = _full_size_checks(rt, orc, renderer, scene, cam, n_probe=32)
     assert img.max() <= 7.0 + 1e-9 and img.mean() > 0.005    # nothing is brighter than the light (emit 7, main.cpp:292)
     # ... and as bench.py times it: the fast order with the two media at their positions in the reference's visiting order
-    # (fused slab test, boxes-in-LDS kernel: F_LDS_BOXES | full feature set | F_FMA_BOX) -- the very same doubles, 2 M pixels x 8 samples
+    # (the hot part of the COMPACT program in LDS, the 2 400 quads in memory: F_LDS_BOXES | F_F32_BOX | full feature set) -- the
+    # very same doubles, 2 M pixels x 8 samples
     info = renderer.upload_fast(scene, cam.center)
-    assert info["exact"] and info["has_media"] and info["n_ordered_items"] == 2 and "1279u" in renderer.kernel_name()
+    assert info["exact"] and info["has_media"] and info["n_ordered_items"] == 2 and "1407u" in renderer.kernel_name()
+    # ... as does the slot program with its boxes in LDS (variant bit 20: f64 boxes, fused slab test)
+    assert "1279u" in renderer.kernel_name(variant=1 << 20)
+    import torch
+    slot = torch.empty((1080, 1920, 3), dtype=torch.float64, device=torch.device("cuda", 0))
+    renderer.render_device(cam, slot.data_ptr(), 0, variant=1 << 20)
+    torch.cuda.synchronize()
+    assert np.array_equal(slot.cpu().numpy(), img)
     fast = _full_size_checks(rt, orc, renderer, scene, cam, n_probe=8, probe_seed=5)
     assert np.array_equal(fast, img)
 

@@ -207,7 +207,9 @@ typedef struct rtk_render_opts {
                              * bits 8-13 = scheduler loop-exit thresholds, bits 14-16 = refill batch size, bits 17-19 = lanes needed
                              * for a sphere step inside the box loop, bit 20 = f64 boxes instead of the MIXED program, bit 21 = no boxes-in-LDS
                              * kernel for programs larger than LDS (see csrc/rtk_trace.hip); bit 22 = write the compact tile
-                             * buffer [tiles][3][64] also when n_ranks == 1 (rtk_multi's one-device RCCL path; d_rgb8 NULL) */
+                             * buffer [tiles][3][64] also when n_ranks == 1 (rtk_multi's one-device RCCL path; d_rgb8 NULL);
+                             * bit 23 = the hot/cold form of a COMPACT program (quads and triangles in memory, the rest in
+                             * LDS) although the whole program would fit (tests) */
     void* stream;           /* hipStream_t, NULL = default stream */
 } rtk_render_opts;
 

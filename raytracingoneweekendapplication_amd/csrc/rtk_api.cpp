@@ -822,7 +822,9 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
             if ((rc = out.upload(units, &out.view.program_compact)) != RTK_OK) return rc;
             if ((rc = out.upload(ranks, &out.view.tie_rank)) != RTK_OK) return rc;
             out.view.n_units16 = int32_t(units.size());
-            if (units.size() * sizeof(Unit16) + mats.size() * sizeof(MaterialRec<real>) > size_t(kLdsBytesPerCU)) {
+            // the same program in its hot/cold form: for programs too large for LDS -- and, through variant bit 23, for tests
+            // of that form on scenes small enough for the oracle (only the full-feature kernel family has it)
+            if ((prog.features & ~kFeatQuadBox) != 0 && (prog.features & ~kFeatMesh) != 0) {
                 std::vector<Unit16> hot, cold;
                 std::vector<uint32_t> ranks_by_id;
                 build_hot_cold_program(sc, prog, eye_extent, hot, cold, ranks_by_id);
@@ -1231,7 +1233,7 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
     }
     unsigned char* d_cam = ctx->d_cameras + cslot * kCameraStride;
     const bool allow_lds = (opts->variant & 1) == 0;  // variant bit 0: keep the program in global memory (A/B)
-    const uint32_t diag = uint32_t(opts->variant) & 0x3FFF00u;  // bits 8..21: scheduler policy / program layout A/B used by tools/ only
+    const uint32_t diag = uint32_t(opts->variant) & 0xBFFF00u;  // bits 8..21, 23: scheduler policy / program layout A/B used by tools/ and tests only
     hipError_t e;
     if (opts->real_mode == RTK_REAL_F64) {
         if (!cam_cached) {
@@ -1372,7 +1374,7 @@ int rtk_scene_info(rtk_ctx* ctx, int32_t* n_program_ops, int64_t* bytes_f64, int
 const char* rtk_kernel_name(rtk_ctx* ctx, int real_mode, int variant) {
     if (!ctx || !ctx->has_scene) return "";
     const bool allow_lds = (variant & 1) == 0;
-    const uint32_t diag = uint32_t(variant) & 0x3FFF00u;
+    const uint32_t diag = uint32_t(variant) & 0xBFFF00u;
     return real_mode == RTK_REAL_F64 ? render_kernel_name<double>(ctx->scene64.view, ctx->features, false, allow_lds, diag)
                                      : render_kernel_name<float>(ctx->scene32.view, ctx->features, false, allow_lds, diag);
 }

@@ -2182,7 +2182,7 @@ static KernelChoice choose_kernel(const SceneView<real>& sc, uint32_t features, 
         // Msamples/s (there the coordinates run into the thousands -- a fog boundary of radius 5000 -- and the 2^-19 x extent
         // margin exceeds a quad's own box thickness: +55 % quad tests).
         const size_t bytes = size_t(sc.n_units16) * sizeof(Unit16) + size_t(sc.n_materials) * sizeof(MaterialRec<real>);
-        if (!(allow_lds && bytes <= size_t(kLdsBytesPerCU))) {
+        if (!(allow_lds && bytes <= size_t(kLdsBytesPerCU)) || (diag & (1u << 23)) != 0) {  // (variant bit 23: the hot/cold form although the whole would fit)
             // ... unless its hot part does (COLD kernels: quads and triangles stay in memory, everything else in LDS) -- full-feature family, timed kernels
             const size_t hot = size_t(sc.n_hot_units) * sizeof(Unit16) + size_t(sc.n_materials) * sizeof(MaterialRec<real>);
             const uint32_t scene = features & ~uint32_t(F_FMA_BOX | F_MATTE);

@@ -399,6 +399,16 @@ def test_fast_order_on_the_device(rt, orc, renderer, scenes, case):
     slot_fast, _, _ = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, variant=1 << 20)
     in_global, _, _ = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, variant=1)
     assert np.array_equal(slot_fast, gpu) and np.array_equal(in_global, gpu)
+    # the hot/cold form of the COMPACT program (what programs larger than LDS run from: quads and triangles -- in runs, also
+    # inside a medium's boundary and under instance transforms -- in memory, everything else in LDS): forced by variant bit
+    # 23 on the scenes of the full-feature kernel family, which is the only one that has it
+    cold_name = renderer.kernel_name(variant=1 << 23)
+    if int(cold_name.split(",")[1].strip().rstrip("u")) & ~(1024 | 256 | 128) == 127:
+        assert "1407u" in cold_name
+        cold_img, cold8, _ = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, variant=1 << 23)
+        assert np.array_equal(cold_img, gpu) and np.array_equal(cold8, gpu8)
+    else:
+        assert name in ("three_spheres", "book1_final", "cornell_box", "mesh", "obj_mesh")
     assert fast.exact   # media included: they keep their position in the reference's visiting order
     renderer.upload(scene)
     base, base8, bcnt = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, count=True)

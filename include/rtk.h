@@ -280,10 +280,10 @@ typedef struct rtk_optimize_opts {
     int32_t has_eye;        /* != 0: order children by distance to `eye` (camera::center, Camera.txt:125) */
     int32_t max_leaf;       /* most primitives tested in a row without a box of their own (0 = 4) */
     rtk_vec3 eye;
-    double prim_cost_scale; /* scales the cost of a primitive test relative to a slab test in the SAH.  0 = automatic: 1.0
-                             * for scenes with quads; scenes of spheres and triangles are re-grouped at 1.5 (then 1.4,
-                             * 1.2) as long as the resulting program still fits one CU's LDS (more boxes, fewer primitive
-                             * tests: C4 66.0 -> 63.5 ms) */
+    double prim_cost_scale; /* scales the cost of a primitive test relative to a slab test in the SAH.  0 = automatic: the
+                             * largest of a short list of scales (from 1.5 without quads, 2.0 with) whose program the f64
+                             * kernels can keep in one CU's LDS -- whole, or at least its hot part (everything but quads
+                             * and triangles), or at least the box records (see rtk_optimize.cpp) */
     int32_t free_media_order; /* 0 (default): a constant_medium keeps its position in the reference's visiting order -- it is
                                * called after exactly the objects that precede it there -- so it meets the same interval
                                * and draws the same random numbers as in the reference: the image stays bit-identical

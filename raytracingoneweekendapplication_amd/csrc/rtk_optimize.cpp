@@ -866,7 +866,7 @@ static void slot_program_counts(const rtk_scene_desc& d, size_t& n_slots, size_t
 //    primitive tests, which is what pays once everything is read from LDS (C4: 66.0 -> 63.5 ms, C2: 21.31 -> 21.23) -- as
 //    long as its COMPACT program still fits one CU's LDS: a program that has to leave LDS loses far more than the better
 //    hierarchy gains (C4 at 1.6x: 175 ms), so the scale steps down (1.4, 1.2, 1.0) until it fits.  Scenes with quads start
-//    at 1.0 (the Cornell box is flat between 1.0 and 1.5 and worse in between);
+//    at 2.0 (the Cornell box: 27.4 ms at 1.0 and 1.5, 26.75 at 1.75-2.0, 27.0 at 2.5-3, 27.3 from 4 on), then 1.0;
 //  * a program too large for that (C5: 2 400 quads of 144 bytes) keeps its HOT part there -- boxes, spheres, everything
 //    but the quads and triangles, which stay in memory (SceneView::program_hot) -- and primitive tests are priced DOWN
 //    step by step (fewer, larger leaves: fewer boxes) until that part fits; failing that, until at least the box
@@ -879,12 +879,14 @@ int rtk_scene_optimize(const rtk_scene_desc* scene, const rtk_optimize_opts* opt
     if (opts_in) o = *opts_in;
     if (o.prim_cost_scale > 0) return optimize_once(scene, &o, out_scene, info);
     const size_t budget = size_t(160) * 1024 - 2048;  // the kernel's own LDS words
-    static const double kScales[] = {1.5, 1.4, 1.2, 1.0, 0.85, 0.7, 0.6, 0.5, 0.4};
-    const int n_scales = int(sizeof kScales / sizeof kScales[0]);
+    static const double kScalesNoQuads[] = {1.5, 1.4, 1.2, 1.0, 0.85, 0.7, 0.6, 0.5, 0.4};
+    static const double kScalesQuads[] = {2.0, 1.0, 0.85, 0.7, 0.6, 0.5, 0.4};
+    const double* kScales = scene->n_quads == 0 ? kScalesNoQuads : kScalesQuads;
+    const int n_scales = scene->n_quads == 0 ? int(sizeof kScalesNoQuads / sizeof kScalesNoQuads[0]) : int(sizeof kScalesQuads / sizeof kScalesQuads[0]);
     const bool full_feature = scene->n_media > 0 || scene->n_translates > 0 || scene->n_rotates > 0;  // only those kernels have the hot/cold form
     rtk_scene_desc* fallback = nullptr;  // the first hierarchy whose slot program at least keeps its boxes in LDS
     rtk_optimize_info fallback_info;
-    for (int k = scene->n_quads == 0 ? 0 : 3; k < n_scales; k++) {
+    for (int k = 0; k < n_scales; k++) {
         o.prim_cost_scale = kScales[k];
         rtk_optimize_info local;
         rtk_scene_desc* candidate = nullptr;

@@ -23,10 +23,12 @@ N grows, so scaling is "strong".
 
 Visiting order: by default ("--order auto") the scene is rendered in the fast order of
 rtk_scene_optimize (same primitives, SAH grouping, fewer aabb::hit calls per ray) when
-that is provably bit-identical to the reference's bvh_node order (no constant_medium, no
-triangle: C2, C3), otherwise in the reference order.  The other order is rendered too,
-outside the timed region, and reported under "other_order" with its own rate; when the
-fast order claims exactness the two framebuffers must be byte-identical or the run fails.
+the pass reports it bit-identical to the reference's bvh_node order -- it does for every
+BASELINE config: exact ties follow the reference's visiting ranks, constant media keep
+their positions in the reference's order -- otherwise in the reference order.  The other
+order is rendered too, outside the timed region, and reported under "other_order" with
+its own rate; when the fast order claims exactness the two framebuffers must be
+byte-identical or the run fails.
 
 The headline dtype is f64: the reference computes in double (vec3.h:7) and the
 parity bar (RMSE < 1e-4 against the CPU at matched seed) is only meaningful at

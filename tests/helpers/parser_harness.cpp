@@ -29,6 +29,10 @@ static unsigned long long fnv(const unsigned char* p, size_t n) {
     return h;
 }
 
+namespace rtk {
+size_t hot_program_lds_bytes(const rtk_scene_desc* scene);  // csrc/rtk_api.cpp (internal; what rtk_scene_optimize sizes the LDS part with)
+}
+
 int main(int argc, char** argv) {
     if (argc < 3) {
         std::fprintf(stderr, "usage: %s image|obj|rtks <file>...\n", argv[0]);
@@ -63,8 +67,10 @@ int main(int argc, char** argv) {
                 if (rc_opt == RTK_OK) {
                     int32_t fast_ops = 0;
                     rc_opt = rtk_scene_validate(fast, &fast_ops);
+                    (void)rtk::hot_program_lds_bytes(fast);  // the hot/cold program builder (build_hot_cold_program) on every accepted scene
                     rtk_scene_optimized_free(fast);
                 }
+                (void)rtk::hot_program_lds_bytes(&st.desc);
             }
             std::printf("%s: validate %d (%d ops) optimize %d\n", path, rc, ops, rc_opt);
         } else {

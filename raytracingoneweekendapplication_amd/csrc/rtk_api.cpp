@@ -358,13 +358,13 @@ static void build_mixed_program(const rtk_scene_desc& sc, const Program& prog, d
         if (kind == OP_BOX) {
             const rtk_aabb& b = sc.bvh_boxes[payload];
             const double m = box_margin(b, margin);
-            rec->f[0] = round_down(b.xmin - m); rec->f[1] = round_up(b.xmax + m);
-            rec->f[2] = round_down(b.ymin - m); rec->f[3] = round_up(b.ymax + m);
-            rec->f[4] = round_down(b.zmin - m); rec->f[5] = round_up(b.zmax + m);
+            rec->set_f(0, round_down(b.xmin - m)); rec->set_f(1, round_up(b.xmax + m));
+            rec->set_f(2, round_down(b.ymin - m)); rec->set_f(3, round_up(b.ymax + m));
+            rec->set_f(4, round_down(b.zmin - m)); rec->set_f(5, round_up(b.zmax + m));
             rec->aux = unit_of_op[op.aux];
         } else if (kind == OP_SPHERE || kind == OP_SPHERE_MOVING) {
             const rtk_sphere& s = sc.spheres[payload];
-            rec->d[0] = s.center0.x; rec->d[1] = s.center0.y; rec->d[2] = s.center0.z;
+            rec->set_d(0, s.center0.x); rec->set_d(1, s.center0.y); rec->set_d(2, s.center0.z);
             double* cont = reinterpret_cast<double*>(rec + 1);
             cont[0] = s.radius;
             cont[1] = 1.0 / s.radius;
@@ -429,16 +429,16 @@ static void write_compact_record(const rtk_scene_desc& sc, const Program& prog, 
         case OP_BOX: {
             const rtk_aabb& b = sc.bvh_boxes[payload];
             const double m = box_margin(b, margin);
-            head->f[0] = round_down(b.xmin - m); head->f[1] = round_up(b.xmax + m);
-            head->f[2] = round_down(b.ymin - m); head->f[3] = round_up(b.ymax + m);
-            head->f[4] = round_down(b.zmin - m); head->f[5] = round_up(b.zmax + m);
+            head->set_f(0, round_down(b.xmin - m)); head->set_f(1, round_up(b.xmax + m));
+            head->set_f(2, round_down(b.ymin - m)); head->set_f(3, round_up(b.ymax + m));
+            head->set_f(4, round_down(b.zmin - m)); head->set_f(5, round_up(b.zmax + m));
             head->aux = unit_of_link[op.aux];
             break;
         }
         case OP_SPHERE:
         case OP_SPHERE_MOVING: {
             const rtk_sphere& s = sc.spheres[payload];
-            head->d[0] = s.center0.x; head->d[1] = s.center0.y; head->d[2] = s.center0.z;
+            head->set_d(0, s.center0.x); head->set_d(1, s.center0.y); head->set_d(2, s.center0.z);
             more[0] = s.radius;
             more[1] = 1.0 / s.radius;  // the factor of `(p - center) / radius` (vec3.h:91-93), once instead of per hit
             if (kind == OP_SPHERE_MOVING) { more[2] = s.center_dir.x; more[3] = s.center_dir.y; more[4] = s.center_dir.z; }
@@ -449,7 +449,7 @@ static void write_compact_record(const rtk_scene_desc& sc, const Program& prog, 
             const rtk_quad& q = sc.quads[payload];
             const double vals[16] = {q.normal.x, q.normal.y, q.normal.z, q.D, q.Q.x, q.Q.y, q.Q.z, q.w.x, q.w.y, q.w.z,
                                      q.v.x, q.v.y, q.v.z, q.u.x, q.u.y, q.u.z};
-            for (int e = 0; e < 3; e++) head->d[e] = vals[e];
+            for (int e = 0; e < 3; e++) head->set_d(e, vals[e]);
             for (int e = 3; e < 16; e++) more[e - 3] = vals[e];
             with_material(q.material);
             break;
@@ -459,19 +459,19 @@ static void write_compact_record(const rtk_scene_desc& sc, const Program& prog, 
             // v0v1 = p1 - p0, v0v2 = p2 - p0 (triangle.h:67-68) in double
             const double vals[9] = {t.p2.x - t.p0.x, t.p2.y - t.p0.y, t.p2.z - t.p0.z, t.p1.x - t.p0.x, t.p1.y - t.p0.y, t.p1.z - t.p0.z,
                                     t.p0.x, t.p0.y, t.p0.z};
-            for (int e = 0; e < 3; e++) head->d[e] = vals[e];
+            for (int e = 0; e < 3; e++) head->set_d(e, vals[e]);
             for (int e = 3; e < 9; e++) more[e - 3] = vals[e];
             with_material(t.material);
             break;
         }
         case OP_MED_MID: head->aux = unit_of_link[op.aux]; break;
         case OP_MED_END:
-            head->d[0] = sc.media[payload].neg_inv_density;
+            head->set_d(0, sc.media[payload].neg_inv_density);
             with_material(sc.media[payload].material);
             break;
         case OP_MED_SPHERE: {
             const rtk_sphere& s = sc.spheres[prog.extra[i]];
-            head->d[0] = s.center0.x; head->d[1] = s.center0.y; head->d[2] = s.center0.z;
+            head->set_d(0, s.center0.x); head->set_d(1, s.center0.y); head->set_d(2, s.center0.z);
             more[0] = s.radius;
             more[1] = sc.media[payload].neg_inv_density;
             with_material(sc.media[payload].material);

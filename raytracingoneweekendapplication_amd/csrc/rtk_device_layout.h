@@ -98,11 +98,19 @@ inline constexpr int slots_of(uint32_t kind) {
 //   OP_END            1 unit
 // A culling box only decides which primitives get tested; the tests themselves, and so the hit, stay exact f64.
 struct alignas(16) MixedHead {
-    union {
-        float f[6];
-        double d[3];
-    };
+    // a box: six floats xmin, xmax, ymin, ymax, zmin, zmax; any other record: its first three payload doubles.  Plain words
+    // with bit-cast accessors rather than a union: a union read under both types keeps a stack copy of the record alive in
+    // the kernels (six dead scratch stores around every box loop in the ISA of the lean MIXED kernel).
+    uint32_t w[6];
     uint32_t kind_payload, aux;
+    constexpr float f(int k) const { return __builtin_bit_cast(float, w[k]); }
+    constexpr double d(int k) const { return __builtin_bit_cast(double, (unsigned long long)(w[2 * k]) | ((unsigned long long)(w[2 * k + 1]) << 32)); }
+    void set_f(int k, float x) { w[k] = __builtin_bit_cast(uint32_t, x); }
+    void set_d(int k, double x) {
+        const unsigned long long v = __builtin_bit_cast(unsigned long long, x);
+        w[2 * k] = uint32_t(v);
+        w[2 * k + 1] = uint32_t(v >> 32);
+    }
 };
 static_assert(sizeof(MixedHead) == 32, "mixed unit size");
 inline constexpr int mixed_units(uint32_t kind) { return kind == OP_SPHERE ? 2 : (kind == OP_SPHERE_MOVING ? 3 : 1); }

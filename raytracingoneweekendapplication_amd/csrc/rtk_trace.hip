@@ -548,9 +548,9 @@ RTK_DEV void hit_tri(Lane<real>& L, const Rec* __restrict__ rec, uint32_t units,
 // Conservative slab test in float: the same min/max structure as slab_test_fma on bounds that were rounded outward
 // and grown for exactly this arithmetic.  v_max3/v_min3 fold the reduction.
 RTK_DEV bool slab_test32(const MixedHead& b, V3<float> oi, V3<float> inv, float tmin, float tmax) {
-    const float t0x = __builtin_fmaf(b.f[0], inv.x, -oi.x), t1x = __builtin_fmaf(b.f[1], inv.x, -oi.x);
-    const float t0y = __builtin_fmaf(b.f[2], inv.y, -oi.y), t1y = __builtin_fmaf(b.f[3], inv.y, -oi.y);
-    const float t0z = __builtin_fmaf(b.f[4], inv.z, -oi.z), t1z = __builtin_fmaf(b.f[5], inv.z, -oi.z);
+    const float t0x = __builtin_fmaf(b.f(0), inv.x, -oi.x), t1x = __builtin_fmaf(b.f(1), inv.x, -oi.x);
+    const float t0y = __builtin_fmaf(b.f(2), inv.y, -oi.y), t1y = __builtin_fmaf(b.f(3), inv.y, -oi.y);
+    const float t0z = __builtin_fmaf(b.f(4), inv.z, -oi.z), t1z = __builtin_fmaf(b.f(5), inv.z, -oi.z);
     const float nx = raw_min(t0x, t1x), fx = raw_max(t0x, t1x);
     const float ny = raw_min(t0y, t1y), fy = raw_max(t0y, t1y);
     const float nz = raw_min(t0z, t1z), fz = raw_max(t0z, t1z);
@@ -573,9 +573,9 @@ RTK_DEV float pick(float a, float b, unsigned long long mask) {  // lane-wise: m
     return r;
 }
 RTK_DEV bool slab_test32_signed(const MixedHead& b, V3<float> oi_hi, V3<float> oi_lo, V3<float> inv, float tmin, float tmax, const SignMasks& m) {
-    const float nx = __builtin_fmaf(pick(b.f[0], b.f[1], m.x), inv.x, -oi_hi.x), fx = __builtin_fmaf(pick(b.f[1], b.f[0], m.x), inv.x, -oi_lo.x);
-    const float ny = __builtin_fmaf(pick(b.f[2], b.f[3], m.y), inv.y, -oi_hi.y), fy = __builtin_fmaf(pick(b.f[3], b.f[2], m.y), inv.y, -oi_lo.y);
-    const float nz = __builtin_fmaf(pick(b.f[4], b.f[5], m.z), inv.z, -oi_hi.z), fz = __builtin_fmaf(pick(b.f[5], b.f[4], m.z), inv.z, -oi_lo.z);
+    const float nx = __builtin_fmaf(pick(b.f(0), b.f(1), m.x), inv.x, -oi_hi.x), fx = __builtin_fmaf(pick(b.f(1), b.f(0), m.x), inv.x, -oi_lo.x);
+    const float ny = __builtin_fmaf(pick(b.f(2), b.f(3), m.y), inv.y, -oi_hi.y), fy = __builtin_fmaf(pick(b.f(3), b.f(2), m.y), inv.y, -oi_lo.y);
+    const float nz = __builtin_fmaf(pick(b.f(4), b.f(5), m.z), inv.z, -oi_hi.z), fz = __builtin_fmaf(pick(b.f(5), b.f(4), m.z), inv.z, -oi_lo.z);
     const float near = raw_max(raw_max3(nx, ny, nz), tmin);
     const float far = raw_min(raw_min3(fx, fy, fz), tmax);
     return far >= near;
@@ -601,7 +601,7 @@ template <bool XF = false, uint32_t UNITS = 1, typename real, bool COUNT>
 RTK_DEV void step_box_mixed_exact(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cnt) {
     cnt.inc(C_BOX);
     Slot<real> b;
-    for (int k = 0; k < 6; k++) b.v[k] = real(rec.f[k]);
+    for (int k = 0; k < 6; k++) b.v[k] = real(rec.f(k));
     const V3<real> d = ray_d<XF>(L);
     const V3<real> inv = mk(real(1) / d.x, real(1) / d.y, real(1) / d.z);
     const bool hit = slab_test<true>(b, ray_o<XF>(L), inv, L.tmin, L.best_t);
@@ -611,12 +611,12 @@ RTK_DEV void step_box_mixed_exact(Lane<real>& L, const MixedHead& rec, Counters<
 template <typename real, bool COUNT, typename Tie>
 RTK_DEV void step_sphere_mixed(Lane<real>& L, const MixedHead& head, const MixedHead* __restrict__ rec, Counters<COUNT>& cnt, const Tie& tie) {
     const double radius = reinterpret_cast<const double*>(rec + 1)[0];
-    hit_sphere<false, true>(L, mk(real(head.d[0]), real(head.d[1]), real(head.d[2])), real(radius), 2u, cnt, tie);
+    hit_sphere<false, true>(L, mk(real(head.d(0)), real(head.d(1)), real(head.d(2))), real(radius), 2u, cnt, tie);
 }
 // ... and on a COMPACT record (3 units): the head (centre) is usually in registers already, the radius follows it.
 template <bool XF, typename real, bool COUNT, typename Tie>
 RTK_DEV void step_sphere_compact(Lane<real>& L, const MixedHead& head, const Unit16* __restrict__ rec, Counters<COUNT>& cnt, const Tie& tie) {
-    hit_sphere<XF, true>(L, mk(real(head.d[0]), real(head.d[1]), real(head.d[2])), packed<real, 3>(rec), 3u, cnt, tie);
+    hit_sphere<XF, true>(L, mk(real(head.d(0)), real(head.d(1)), real(head.d(2))), packed<real, 3>(rec), 3u, cnt, tie);
 }
 // The remaining record kinds of a sphere-only program: a moving sphere, or a box for an irregular ray.
 template <typename real, bool COUNT, typename Tie>
@@ -626,7 +626,7 @@ RTK_DEV void step_other_mixed(Lane<real>& L, const MixedHead* __restrict__ rec, 
         step_box_mixed_exact(L, *rec, cnt);
     } else if (kind == OP_SPHERE_MOVING) {
         const double* cont = reinterpret_cast<const double*>(rec + 1);
-        const V3<real> cc = mk(real(rec->d[0]), real(rec->d[1]), real(rec->d[2])) + scale(L.tm, mk(real(cont[2]), real(cont[3]), real(cont[4])));
+        const V3<real> cc = mk(real(rec->d(0)), real(rec->d(1)), real(rec->d(2))) + scale(L.tm, mk(real(cont[2]), real(cont[3]), real(cont[4])));
         hit_sphere<false, true>(L, cc, real(cont[0]), 3u, cnt, tie);
     } else {
         L.pc += uint32_t(mixed_units(kind));  // unreachable for a validated sphere-only program
@@ -840,6 +840,30 @@ RTK_DEV V3<real> material_color(const SceneView<real>& sc, const MaterialRec<rea
     return texture_value(sc, m.tex, u, v, p, cnt);
 }
 
+#ifdef RTK_PROFILE
+// Profile build: shade's sub-phases, accumulated per wave (flushed to counters[kShadeProfBase + 2 k] cycles / [.. + 1]
+// calls: k = 0 the deferred hit record, 1 materials and textures, 2 the miss path in front of them, 3 the scattered ray).
+struct ShadeProf {
+    unsigned long long t[4] = {0, 0, 0, 0}, n[4] = {0, 0, 0, 0};
+};
+constexpr int kShadeProfBase = 32 + 4 * 4096;
+#define RTK_SHADE_PROF_PARAM , ShadeProf& sprof
+#define RTK_SHADE_PROF_ARG , sprof
+#define RTK_SHADE_PROF_BEGIN unsigned long long sp_prev_ = __builtin_amdgcn_s_memtime();
+#define RTK_SHADE_PROF(k)                                             \
+    {                                                                 \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        sprof.t[k] += now_ - sp_prev_;                                \
+        sprof.n[k] += 1;                                              \
+        sp_prev_ = now_;                                              \
+    }
+#else
+#define RTK_SHADE_PROF_PARAM
+#define RTK_SHADE_PROF_ARG
+#define RTK_SHADE_PROF_BEGIN
+#define RTK_SHADE_PROF(k)
+#endif
+
 // ------------------------------------------------------------------ shading ---
 template <typename real>
 struct Surface {  // hit_record (hittable.h:11-27)
@@ -859,7 +883,7 @@ RTK_DEV void make_surface_mixed(const MixedHead* __restrict__ prog, uint32_t bes
     sf.p = wo + scale(t, wd);
     sf.u = real(0);
     sf.v = real(0);
-    V3<real> cc = mk(real(rec->d[0]), real(rec->d[1]), real(rec->d[2]));
+    V3<real> cc = mk(real(rec->d(0)), real(rec->d(1)), real(rec->d(2)));
     if (kind == OP_SPHERE_MOVING) cc = cc + scale(tm, mk(real(cont[2]), real(cont[3]), real(cont[4])));
     const V3<real> outward = scale(real(cont[1]), sf.p - cc);
     sf.front_face = dot(wd, outward) < real(0);
@@ -981,15 +1005,18 @@ RTK_DEV void begin_sample(Lane<real>& L, const CameraRec<real>& cam, int i, int 
 // `hit_rec` = the record of the closest hit (program + L.best_pc; anything when there is none).
 template <typename real, uint32_t FEAT, bool COUNT, typename ProgT>
 RTK_DEV bool shade(Lane<real>& L, const ProgT* __restrict__ hit_rec, const SceneView<real>& sc, const MaterialRec<real>* __restrict__ mats,
-                   const CameraRec<real>& cam, Counters<COUNT>& cnt) {
+                   const CameraRec<real>& cam, Counters<COUNT>& cnt RTK_SHADE_PROF_PARAM) {
+    RTK_SHADE_PROF_BEGIN
     if (L.best_pc == kNoHit) {  // Camera.txt:211-213
         L.radiance = L.radiance + L.throughput * ld3(cam.background);
         return true;
     }
     cnt.inc(C_SURFACE);
+    RTK_SHADE_PROF(2)
     Surface<real> sf;
     if constexpr (std::is_same_v<ProgT, MixedHead>) make_surface_mixed(hit_rec, 0u, L.best_t, L.ro, L.rd, L.tm, sf);  // lean MIXED program
     else make_surface<real, FEAT>(hit_rec, sc, mats, 0u, L.best_t, L.ro, L.rd, L.tm, sf);                             // slot or COMPACT program
+    RTK_SHADE_PROF(0)
     const MaterialRec<real>& m = mats[sf.material];
     const V3<real> rd = L.rd;
 
@@ -1069,6 +1096,7 @@ RTK_DEV bool shade(Lane<real>& L, const ProgT* __restrict__ hit_rec, const Scene
         }
         return true;
     }
+    RTK_SHADE_PROF(1)
     if (!scattered) return true;  // Camera.txt:223-225 (emission of a scattering material is zero)
     if ((FEAT & F_LIGHTS) && sc.n_lights > 0) {  // Camera.txt:228
         V3<real> lighting = attenuation * point_lighting(sc, sf.p, sf.normal);
@@ -1078,6 +1106,7 @@ RTK_DEV bool shade(Lane<real>& L, const ProgT* __restrict__ hit_rec, const Scene
     L.ro = sf.p;
     L.rd = next_d;
     L.depth -= 1;
+    RTK_SHADE_PROF(3)
     return L.depth <= 0;  // Camera.txt:205-206: the next ray_color call returns black
 }
 
@@ -1130,10 +1159,11 @@ RTK_DEV int popcount64(unsigned long long m) {
 // library): s_memtime stamps at the scheduler's phase boundaries; per phase the wave adds its cycles,
 // step count and active-lane count to counters[3*phase .. 3*phase+2].  The product build has none of it.
 #ifdef RTK_PROFILE
-#define RTK_PROF_DECL unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_n[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_l[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+#define RTK_PROF_DECL unsigned long long prof_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_n[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_l[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
     unsigned long long prof_prev = __builtin_amdgcn_s_memtime();                                                                       \
     const unsigned long long prof_wall0 = wall_clock64();                                                                              \
-    unsigned long long prof_wall_empty = 0, prof_chunk_t0 = 0;
+    unsigned long long prof_wall_empty = 0, prof_chunk_t0 = 0;                                                                         \
+    ShadeProf sprof;
 #define RTK_PROF_CHUNK_BEGIN prof_chunk_t0 = wall_clock64();
 #define RTK_PROF_CHUNK_END /* (pixel, chunk)s that ended after the work queue ran dry and took over 300 us: [31] count, then {begin, duration, segments, slot << 8 | pixel} from [32] on */ \
     {                                                                                                                                  \
@@ -1160,8 +1190,13 @@ RTK_DEV int popcount64(unsigned long long m) {
     }
 #define RTK_PROF_FLUSH                                                        \
     if (lane == 0)                                                            \
-        for (int ph_ = 0; ph_ < 8; ph_++) { /* phases 6, 7 (parts of the shade step) live at [25..30] */ \
-            const int at_ = ph_ < 6 ? 3 * ph_ : 25 + 3 * (ph_ - 6);          \
+        for (int k_ = 0; k_ < 4; k_++) {                                      \
+            atomicAdd(&counters[kShadeProfBase + 2 * k_], sprof.t[k_]);       \
+            atomicAdd(&counters[kShadeProfBase + 2 * k_ + 1], sprof.n[k_]);   \
+        }                                                                     \
+    if (lane == 0)                                                            \
+        for (int ph_ = 0; ph_ < 10; ph_++) { /* phases 6, 7 (parts of the shade step) live at [25..30], 8 and 9 behind the shade sub-phases */ \
+            const int at_ = ph_ < 6 ? 3 * ph_ : (ph_ < 8 ? 25 + 3 * (ph_ - 6) : kShadeProfBase + 8 + 3 * (ph_ - 8)); \
             atomicAdd(&counters[at_], prof_t[ph_]);                           \
             atomicAdd(&counters[at_ + 1], prof_n[ph_]);                       \
             atomicAdd(&counters[at_ + 2], prof_l[ph_]);                       \
@@ -1788,9 +1823,11 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
 #if RTK_AB_SHADE_PRIO
             __builtin_amdgcn_s_setprio(RTK_AB_SHADE_PRIO);
 #endif
+            RTK_PROF_MARK(8, 1, 0)   // profile build: from the vote to here
             if (kind == OP_END) {
                 alive = true;
-                const bool ended = L.depth <= 0 || shade<real, FEAT, COUNT>(L, record_of(L.best_pc), sc, mats, cam, cnt);
+                const bool ended = L.depth <= 0 || shade<real, FEAT, COUNT>(L, record_of(L.best_pc), sc, mats, cam, cnt RTK_SHADE_PROF_ARG);
+                RTK_PROF_MARK(9, 1, 0)   // ... ray_color itself; what follows (the sample's sum, a finished pixel) is booked under phase 3
                 if (ended) {  // pixel_color += ray_color(...) (Camera.txt:72)
                     L.sum = L.sum + L.radiance;
                     L.s += 1;

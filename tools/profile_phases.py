@@ -37,7 +37,7 @@ print("order:", "fast" if use_fast else "reference")
 dev = torch.device("cuda", 0)
 H, W = cam.image_height, cam.image_width
 img = torch.empty((H, W, 3), dtype=torch.float64 if real == rt.RTK_REAL_F64 else torch.float32, device=dev)  # large enough for any shard
-prof = torch.zeros(32 + 4 * 4096, dtype=torch.int64, device=dev)
+prof = torch.zeros(32 + 4 * 4096 + 16, dtype=torch.int64, device=dev)
 # the profile build writes its counters through the d_counters pointer of the (non-counting) kernel
 lib = rt.hip_lib()
 import ctypes as C
@@ -52,14 +52,18 @@ for k in range(3):
 ms = e0.elapsed_time(e1)
 raw = prof.cpu().numpy()
 import numpy as np
-v = np.concatenate([raw[:18], raw[25:31]]).reshape(8, 3).astype(float)
+v = np.concatenate([raw[:18], raw[25:31], raw[32 + 4 * 4096 + 8:32 + 4 * 4096 + 14]]).reshape(10, 3).astype(float)
 total = v[:, 0].sum()
-names = ["refill+vote", "box step", "sphere step", "shade: ray_color", "other op", "quad/tri step", "shade: new sample", "shade: new segment"]
+names = ["refill+vote", "box step", "sphere step", "shade: after ray_color", "other op", "quad/tri step", "shade: new sample", "shade: new segment", "shade: vote -> entry", "shade: ray_color"]
 print(f"{config} {'f64' if real == rt.RTK_REAL_F64 else 'f32'} {W}x{H}x{cam.samples_per_pixel}: {ms:.2f} ms (instrumented)")
-print(f"{'phase':20s} {'cycles %':>9s} {'steps':>14s} {'cyc/step':>9s} {'lanes/step':>10s}")
+print(f"{'phase':24s} {'cycles %':>9s} {'steps':>14s} {'cyc/step':>9s} {'lanes/step':>10s}")
 for n, (t, steps, lanes) in zip(names, v):
     if steps:
-        print(f"{n:20s} {100 * t / total:9.1f} {int(steps):14d} {t / steps:9.1f} {lanes / steps:10.1f}")
+        print(f"{n:24s} {100 * t / total:9.1f} {int(steps):14d} {t / steps:9.1f} {lanes / steps:10.1f}")
+sub = raw[32 + 4 * 4096:32 + 4 * 4096 + 8].astype(float)
+if sub[1]:
+    print("inside ray_color, as lane 0 saw it (wave-cycles per call of the part x calls = % of all phases): " + ", ".join(
+        f"{n} {sub[2 * k] / max(sub[2 * k + 1], 1):.0f} cyc x {int(sub[2 * k + 1])} = {100 * sub[2 * k] / total:.1f} %" for k, n in enumerate(("hit record", "materials + textures", "miss path", "scattered ray"))))
 waves = int(raw[22])
 if waves:
     span = (int(raw[24]) - ((1 << 62) - int(raw[23]))) / 100.0   # us

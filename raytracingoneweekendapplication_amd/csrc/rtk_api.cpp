@@ -750,6 +750,7 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
     out.view.n_lights = sc.n_lights;
     out.view.n_materials = sc.n_materials;
     out.view.n_perlins = sc.n_perlins;
+    out.view.n_chains = int32_t(chains.size());
     out.view.program_mixed = nullptr;
     out.view.n_units = 0;
     out.view.extent = 0.0f;

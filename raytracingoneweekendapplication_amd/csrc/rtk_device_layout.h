@@ -261,7 +261,7 @@ struct SceneView {  // device pointers, passed to the kernel by value
     const uint32_t* kind_words;
     const uint2* box_rank;
     int32_t n_cached_boxes, n_kind_words, n_rank_words;
-    int32_t n_perlins;
+    int32_t n_perlins, n_chains;
 };
 
 struct TileMap {  // which tiles this launch renders and where the pixels go
@@ -283,6 +283,10 @@ struct TileMap {  // which tiles this launch renders and where the pixels go
     // ... and of the Perlin tables (9 KB each in f64: 256 gradient vectors + three permutations) when they fit as well
     // (0 = they stay in memory): perlin::turb reads 7 x (6 permutation entries + 8 gradients) through a dependent index
     int32_t perlin_lds_offset;
+    // every kernel that stages anything: byte offset of the instance-transform chains (0 = they stay in memory).  apply_chain
+    // walks a record through data-dependent branches -- count, is_rotate[k], then that step's constants: up to six
+    // DEPENDENT reads per chain switch, each an L2 round trip from memory
+    int32_t chains_lds_offset;
 };
 
 // Indices into the uint64 work-counter block (same order as rtk_work_counters).

@@ -147,36 +147,65 @@ RTK_DEV V3<real> random_unit_vector(uint32_t& s, Counters<COUNT>& cnt) {
 
 // ------------------------------------------------------------------ rays ------
 // Object-space ray for a chain of instance transforms (hittable.h:46-49,101-116).
-template <typename real>
+#ifndef RTK_CHAIN_PREFETCH
+#define RTK_CHAIN_PREFETCH 1
+#endif
+template <uint32_t FEAT>
+constexpr bool kChainPrefetch = (FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_LDS_BOXES)) == kFeatAll;
+// The constants of the first two steps of a chain are requested together, in front of the branches that pick them: walking
+// the record step by step costs a dependent read per branch (count, is_rotate[k], that step's constants), and a chain
+// switch is nothing but those reads and two dozen operations.  Longer chains (kMaxChain = 4) finish in the loop.
+// PREFETCH is for the full-feature kernels (C5 44.4 -> 43.6 ms); the quad/box kernels at 128 VGPRs would spill for it
+// (scratch 16 -> 60 B, C3 26.2 -> 26.5 ms).
+template <bool PREFETCH = false, typename real>
 RTK_DEV void apply_chain(const ChainRec<real>* __restrict__ chains, uint32_t chain, V3<real> wo, V3<real> wd, V3<real>& o, V3<real>& d) {
     o = wo;
     d = wd;
     if (chain == 0) return;
     const ChainRec<real>& ch = chains[chain];
     const int n = ch.count;
-    for (int k = 0; k < n; k++) {
-        if (ch.is_rotate[k]) {
-            const real s = ch.a[k], c = ch.b[k];
-            o = mk((c * o.x) - (s * o.z), o.y, (s * o.x) + (c * o.z));
-            d = mk((c * d.x) - (s * d.z), d.y, (s * d.x) + (c * d.z));
+    auto step = [&](int rotate, real a, real b, real c) {
+        if (rotate) {
+            const real sn = a, cs = b;
+            o = mk((cs * o.x) - (sn * o.z), o.y, (sn * o.x) + (cs * o.z));
+            d = mk((cs * d.x) - (sn * d.z), d.y, (sn * d.x) + (cs * d.z));
         } else {
-            o = o - mk(ch.a[k], ch.b[k], ch.c[k]);
+            o = o - mk(a, b, c);
         }
+    };
+    int first = 0;
+    if constexpr (PREFETCH && RTK_CHAIN_PREFETCH) {
+        const int r0 = ch.is_rotate[0], r1 = ch.is_rotate[1];
+        const real a0 = ch.a[0], b0 = ch.b[0], c0 = ch.c[0], a1 = ch.a[1], b1 = ch.b[1], c1 = ch.c[1];
+        if (n > 0) step(r0, a0, b0, c0);
+        if (n > 1) step(r1, a1, b1, c1);
+        first = 2;
     }
+    for (int k = first; k < n; k++) step(ch.is_rotate[k], ch.a[k], ch.b[k], ch.c[k]);
 }
 // Hit point and normal back to world space (hittable.h:55,122-134), innermost first.
-template <typename real>
+template <bool PREFETCH = false, typename real>
 RTK_DEV void unapply_chain(const ChainRec<real>* __restrict__ chains, uint32_t chain, V3<real>& p, V3<real>& n) {
     if (chain == 0) return;
     const ChainRec<real>& ch = chains[chain];
-    for (int k = ch.count - 1; k >= 0; k--) {
-        if (ch.is_rotate[k]) {
-            const real s = ch.a[k], c = ch.b[k];
-            p = mk((c * p.x) + (s * p.z), p.y, (-s * p.x) + (c * p.z));
-            n = mk((c * n.x) + (s * n.z), n.y, (-s * n.x) + (c * n.z));
+    const int count = ch.count;
+    auto step = [&](int rotate, real a, real b, real c) {
+        if (rotate) {
+            const real sn = a, cs = b;
+            p = mk((cs * p.x) + (sn * p.z), p.y, (-sn * p.x) + (cs * p.z));
+            n = mk((cs * n.x) + (sn * n.z), n.y, (-sn * n.x) + (cs * n.z));
         } else {
-            p = p + mk(ch.a[k], ch.b[k], ch.c[k]);
+            p = p + mk(a, b, c);
         }
+    };
+    if constexpr (PREFETCH && RTK_CHAIN_PREFETCH) {
+        const int r0 = ch.is_rotate[0], r1 = ch.is_rotate[1];
+        const real a0 = ch.a[0], b0 = ch.b[0], c0 = ch.c[0], a1 = ch.a[1], b1 = ch.b[1], c1 = ch.c[1];
+        for (int k = count - 1; k >= 2; k--) step(ch.is_rotate[k], ch.a[k], ch.b[k], ch.c[k]);
+        if (count > 1) step(r1, a1, b1, c1);
+        if (count > 0) step(r0, a0, b0, c0);
+    } else {
+        for (int k = count - 1; k >= 0; k--) step(ch.is_rotate[k], ch.a[k], ch.b[k], ch.c[k]);
     }
 }
 
@@ -670,7 +699,7 @@ RTK_DEV void step_other(Lane<real>& L, const Rec* __restrict__ rec, const SceneV
         hit_tri<XF, MIXED>(L, rec, rec_units<real>(rec, kind), cnt, tie);
     } else if ((FEAT & F_XFORM) && kind == OP_CHAIN) {
         cnt.inc(C_XFORM, aux);
-        apply_chain(sc.chains, kp >> 4, L.ro, L.rd, L.o, L.d);
+        apply_chain<kChainPrefetch<FEAT>>(sc.chains, kp >> 4, L.ro, L.rd, L.o, L.d);
         L.a = length_squared(L.d);
         L.inv_a = real(1) / L.a;
         if constexpr (MIXED) {
@@ -905,7 +934,7 @@ RTK_DEV void make_surface(const Rec* __restrict__ prog, const SceneView<real>& s
     const uint32_t chain = (FEAT & F_XFORM) ? (aux & 255u) : 0u;
     sf.material = int(aux >> 8);
     V3<real> o = wo, d = wd;
-    if (FEAT & F_XFORM) apply_chain(sc.chains, chain, wo, wd, o, d);
+    if (FEAT & F_XFORM) apply_chain<kChainPrefetch<FEAT>>(sc.chains, chain, wo, wd, o, d);
     sf.p = o + scale(t, d);
     sf.u = real(0);
     sf.v = real(0);
@@ -947,7 +976,7 @@ RTK_DEV void make_surface(const Rec* __restrict__ prog, const SceneView<real>& s
         sf.front_face = true;
         sf.normal = outward;
     }
-    if (FEAT & F_XFORM) unapply_chain(sc.chains, chain, sf.p, sf.normal);
+    if (FEAT & F_XFORM) unapply_chain<kChainPrefetch<FEAT>>(sc.chains, chain, sf.p, sf.normal);
 }
 
 // get_lighting (Camera.txt:240-272).
@@ -1414,6 +1443,16 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
     const TieCtx<TIE, decltype(kind_of_hit)> tie{TIE ? (COLD ? sc.tie_rank_hot : (MIXED ? sc.tie_rank : sc.tie_rank_slot)) : nullptr, kind_of_hit};
     // The hand-out order of the tiles (learned from the previous frame) is staged behind the program when the host
     // found room for it (tmap.order_in_lds): a lookup per work item from LDS instead of a cold global load.
+    if constexpr ((FEAT & F_XFORM) != 0 && (IN_LDS || LDS_PART)) {
+        if (tmap.chains_lds_offset > 0) {  // instance-transform chains (a few hundred bytes: word by word)
+            const int n4 = sc.n_chains * int(sizeof(ChainRec<real>) / 4);
+            const uint32_t* __restrict__ csrc = reinterpret_cast<const uint32_t*>(sc.chains);
+            uint32_t* cdst = reinterpret_cast<uint32_t*>(lds_program + tmap.chains_lds_offset);
+            for (int k = threadIdx.x; k < n4; k += blockDim.x) cdst[k] = csrc[k];
+            __syncthreads();
+            sc.chains = reinterpret_cast<const ChainRec<real>*>(lds_program + tmap.chains_lds_offset);
+        }
+    }
     const int32_t* lds_order = nullptr;
     if (tmap.order_in_lds && tile_order) {
         int32_t* dst_order = reinterpret_cast<int32_t*>(lds_program + tmap.order_lds_offset);
@@ -2157,6 +2196,18 @@ static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>* c
         if (RTK_SPLIT_PERLIN_IN_LDS && (FEAT & F_TEXTURE) != 0 && perlin_bytes > 0 && pat + perlin_bytes + 64 <= size_t(kLdsBytesPerCU)) {
             tm.perlin_lds_offset = int32_t(pat);
             lds = pat + perlin_bytes;
+        }
+    }
+#ifndef RTK_CHAINS_IN_LDS
+#define RTK_CHAINS_IN_LDS 1
+#endif
+    tm.chains_lds_offset = 0;
+    if constexpr ((FEAT & F_XFORM) != 0 && (IN_LDS || (FEAT & F_LDS_BOXES) != 0)) {
+        const size_t chain_bytes = size_t(sc.n_chains) * sizeof(ChainRec<real>);
+        const size_t cat = (lds + 15) & ~size_t(15);
+        if (RTK_CHAINS_IN_LDS && sc.n_chains > 1 && chain_bytes <= 8192 && cat + chain_bytes + 64 <= size_t(kLdsBytesPerCU)) {
+            tm.chains_lds_offset = int32_t(cat);
+            lds = cat + chain_bytes;
         }
     }
     // room for the tile order behind the program?  (never at the price of a second resident workgroup's LDS)

@@ -1862,11 +1862,10 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
 #if RTK_AB_SHADE_PRIO
             __builtin_amdgcn_s_setprio(RTK_AB_SHADE_PRIO);
 #endif
-            RTK_PROF_MARK(8, 1, 0)   // profile build: from the vote to here
+            RTK_PROF_MARK(8, 1, 0)   // profile build: from the vote to here (marks sit outside divergent code: the profile registers are lane 0's)
             if (kind == OP_END) {
                 alive = true;
                 const bool ended = L.depth <= 0 || shade<real, FEAT, COUNT>(L, record_of(L.best_pc), sc, mats, cam, cnt RTK_SHADE_PROF_ARG);
-                RTK_PROF_MARK(9, 1, 0)   // ... ray_color itself; what follows (the sample's sum, a finished pixel) is booked under phase 3
                 if (ended) {  // pixel_color += ray_color(...) (Camera.txt:72)
                     L.sum = L.sum + L.radiance;
                     L.s += 1;

@@ -54,7 +54,7 @@ raw = prof.cpu().numpy()
 import numpy as np
 v = np.concatenate([raw[:18], raw[25:31], raw[32 + 4 * 4096 + 8:32 + 4 * 4096 + 14]]).reshape(10, 3).astype(float)
 total = v[:, 0].sum()
-names = ["refill+vote", "box step", "sphere step", "shade: after ray_color", "other op", "quad/tri step", "shade: new sample", "shade: new segment", "shade: vote -> entry", "shade: ray_color"]
+names = ["refill+vote", "box step", "sphere step", "shade: ray_color", "other op", "quad/tri step", "shade: new sample", "shade: new segment", "shade: vote -> entry", "(unused)"]
 print(f"{config} {'f64' if real == rt.RTK_REAL_F64 else 'f32'} {W}x{H}x{cam.samples_per_pixel}: {ms:.2f} ms (instrumented)")
 print(f"{'phase':24s} {'cycles %':>9s} {'steps':>14s} {'cyc/step':>9s} {'lanes/step':>10s}")
 for n, (t, steps, lanes) in zip(names, v):

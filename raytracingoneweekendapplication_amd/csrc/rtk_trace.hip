@@ -274,6 +274,15 @@ template <typename real, int E>
 RTK_DEV real packed(const Unit16* rec) {
     return real(reinterpret_cast<const double*>(rec)[E < 3 ? E : E + 1]);
 }
+// ... or over a quad record already in registers (COLD kernels: the whole 144-byte record is requested from memory at
+// once, ahead of quad::hit's early-outs -- read field by field behind them it costs a second round trip to L2).
+struct QuadRegs {
+    double q[18];  // the record's nine units as doubles; q[3] holds the header's bits
+};
+template <typename real, int E>
+RTK_DEV real packed(const QuadRegs* rec) {
+    return real(rec->q[E < 3 ? E : E + 1]);
+}
 template <typename real, int E, typename Rec>
 RTK_DEV V3<real> packed3(const Rec* rec) {
     return V3<real>{packed<real, E>(rec), packed<real, E + 1>(rec), packed<real, E + 2>(rec)};
@@ -1514,8 +1523,20 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             const MixedHead run = head_at(hot);
             const uint32_t at = run.aux + sub * units;
             L.pc = uint32_t(n_records) + at;
-            if constexpr (QUAD) hit_quad<XF, MIXED>(L, reinterpret_cast<const ProgRec*>(cold + at), 0u, cnt, tie);
-            else hit_tri<XF, MIXED>(L, reinterpret_cast<const ProgRec*>(cold + at), 0u, cnt, tie);
+#ifndef RTK_COLD_QUAD_PREFETCH
+#define RTK_COLD_QUAD_PREFETCH 1
+#endif
+            if constexpr (QUAD && RTK_COLD_QUAD_PREFETCH) {
+                QuadRegs regs;
+                const double* __restrict__ src = reinterpret_cast<const double*>(cold + at);
+#pragma unroll
+                for (int e = 0; e < 18; e++) regs.q[e] = src[e];
+                hit_quad<XF, MIXED>(L, &regs, 0u, cnt, tie);
+            } else if constexpr (QUAD) {
+                hit_quad<XF, MIXED>(L, reinterpret_cast<const ProgRec*>(cold + at), 0u, cnt, tie);
+            } else {
+                hit_tri<XF, MIXED>(L, reinterpret_cast<const ProgRec*>(cold + at), 0u, cnt, tie);
+            }
             const bool last = sub + 1u >= (run.kind_payload >> 4);
             L.pc = last ? hot + 2u : (hot | ((sub + 1u) << 24));
             k = last ? kind_of(L.pc) : uint32_t(QUAD ? OP_QUAD : OP_TRI);

@@ -1682,7 +1682,10 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
 #ifndef RTK_UNROLL_COMPACT_MESH
 #define RTK_UNROLL_COMPACT_MESH 4
 #endif
-            constexpr int kBoxUnroll = (SPLIT && RTK_UNROLL_SPLIT > 0) ? RTK_UNROLL_SPLIT
+#ifndef RTK_UNROLL_COLD
+#define RTK_UNROLL_COLD 4   // the hot/cold full-feature kernel: C5 45.8 / 42.9 / 42.2 / 42.5 / 42.8 ms at 1 / 2 / 4 / 6 / 8
+#endif
+            constexpr int kBoxUnroll = COLD ? RTK_UNROLL_COLD : (SPLIT && RTK_UNROLL_SPLIT > 0) ? RTK_UNROLL_SPLIT
                                        : (((MIXED && !COMPACT) || FEAT == (kFeatLean | uint32_t(F_FMA_BOX))) ? RTK_UNROLL_MIXED
                                           : (kFamily == kFeatAll ? 2 : (kFamily == kFeatQuadBox ? (COMPACT ? RTK_UNROLL_COMPACT_QUADBOX : RTK_UNROLL_QUADBOX)
                                                                        : (kFamily == kFeatMesh ? (COMPACT ? RTK_UNROLL_COMPACT_MESH : RTK_UNROLL_MESH) : RTK_UNROLL_LEAN))));

@@ -345,6 +345,7 @@ static void build_mixed_program(const rtk_scene_desc& sc, const Program& prog, d
     }
     extent = double(round_up(extent * 1.0000001));
     const double margin = std::ldexp(extent, -19);  // (A/B on C2: a margin 128 times smaller renders 0.7 % faster -- nothing to gain)
+    (void)margin;
     units.assign(unit_of_op.back(), MixedHead{});
     std::memset(units.data(), 0, units.size() * sizeof(MixedHead));
     rank_of_unit.assign(unit_of_op.back(), 0u);
@@ -357,10 +358,30 @@ static void build_mixed_program(const rtk_scene_desc& sc, const Program& prog, d
         rank_of_unit[unit_of_op[i]] = prog.ranks[i];
         if (kind == OP_BOX) {
             const rtk_aabb& b = sc.bvh_boxes[payload];
+#if RTK_CH_BOX
+            // Centre / half-extent form.  The kernel computes, per axis, tc = fma(c, inv, -oi), near = fma(-h, |inv|, tc),
+            // far = fma(h, |inv|, tc) with inv = v_rcp_f32(float(d)) (relative error <= 2^-24 + 2^-23) and oi = float(o) * inv
+            // (<= 2^-24 + that + 2^-24).  Against the exact planes (c -/+ h - o) / d of the stored box the computed ones are off
+            // by at most [(1.5 + 1) 2^-23 (|c| + h) + (2.5 + 1) 2^-23 |o|] / |d| -- the products' errors plus one final rounding
+            // each of tc and of near / far, both bounded by (|c| + |o| + h) / |d| -- i.e. a plane displaced by less than
+            // 2^-21 (|c| + h) + 2^-20 |o|.  |o| <= extent on every axis (a ray that starts outside never enters the float loop,
+            // rtk_trace.hip begin_culling32), so the half-extent is grown by 2^-21 (|c| + h) + 2^-20 extent, plus the distance
+            // the centre moved when it was rounded to float, and rounded up.
+            const double lo[3] = {b.xmin, b.ymin, b.zmin}, hi[3] = {b.xmax, b.ymax, b.zmax};
+            for (int ax = 0; ax < 3; ax++) {
+                const double c = 0.5 * (lo[ax] + hi[ax]);
+                const float cf = float(c);
+                const double h = std::max(hi[ax] - double(cf), double(cf) - lo[ax]);  // covers [lo, hi] from the float centre
+                const double grown = h + std::ldexp(std::fabs(double(cf)) + h, -21) + std::ldexp(extent, -20) + 1e-300;
+                rec->set_f(ax, cf);
+                rec->set_f(3 + ax, round_up(grown * (1.0 + 1e-7)));
+            }
+#else
             const double m = box_margin(b, margin);
             rec->set_f(0, round_down(b.xmin - m)); rec->set_f(1, round_up(b.xmax + m));
             rec->set_f(2, round_down(b.ymin - m)); rec->set_f(3, round_up(b.ymax + m));
             rec->set_f(4, round_down(b.zmin - m)); rec->set_f(5, round_up(b.zmax + m));
+#endif
             rec->aux = unit_of_op[op.aux];
         } else if (kind == OP_SPHERE || kind == OP_SPHERE_MOVING) {
             const rtk_sphere& s = sc.spheres[payload];

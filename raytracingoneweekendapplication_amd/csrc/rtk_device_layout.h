@@ -37,6 +37,13 @@
 #define RTK_SIGNED_SLAB 1
 #endif
 
+// MIXED program (sphere-only scenes): 1 = a box record holds centre and half-extent, f[0..2] = c, f[3..5] = h, and the slab test
+// is near = (c/d - o/d) - h/|d|, far = (c/d - o/d) + h/|d| -- nine fused multiply-adds (|1/d| is a free source modifier)
+// instead of six selects and six multiply-adds; the half-extent carries the whole float error budget (rtk_api.cpp).
+#ifndef RTK_CH_BOX
+#define RTK_CH_BOX 1
+#endif
+
 namespace rtk {
 
 enum OpKind : uint32_t {
@@ -92,7 +99,8 @@ inline constexpr int slots_of(uint32_t kind) {
 // The MIXED traversal program (F_F32_BOX): records are sequences of 32-byte units, pc counts units.  The first unit of
 // every record carries the header at bytes 24..31, so the kind of the record at pc is always one 8-byte read away:
 //   OP_BOX            1 unit : f[0..5] = xmin,xmax,ymin,ymax,zmin,zmax as floats, rounded OUTWARD and grown (see
-//                              rtk_api.cpp); aux = pc to continue at when the slab test fails
+//                              rtk_api.cpp) -- or, RTK_CH_BOX, centre(3) and half-extent(3), the half-extent rounded up
+//                              and grown; aux = pc to continue at when the slab test fails
 //   OP_SPHERE         2 units: d[0..2] = centre (f64); unit 1 = radius, 1/radius (f64)
 //   OP_SPHERE_MOVING  3 units: as OP_SPHERE; unit 1 also holds dx, dy; unit 2 holds dz (centre2 - centre1)
 //   OP_END            1 unit

@@ -471,12 +471,13 @@ RTK_DEV void sync_interval32(Lane<real>& L) {
 // F_F32_BOX: 1/d and o/d in float for the culling boxes (one v_rcp_f32 per axis instead of an f64 division), and
 // whether the f32 test may be used at all: direction components neither zero nor beyond float range, origin inside
 // the coordinate bound the box margin was sized for (rtk_api.cpp build_mixed_program).
-template <typename real>
+template <bool CH = false, typename real>
 RTK_DEV void begin_culling32(Lane<real>& L, V3<real> o, V3<real> d, float extent) {
     const V3<float> d32 = V3<float>{float(d.x), float(d.y), float(d.z)};
     L.inv32 = V3<float>{__builtin_amdgcn_rcpf(d32.x), __builtin_amdgcn_rcpf(d32.y), __builtin_amdgcn_rcpf(d32.z)};
     L.oi32 = V3<float>{float(o.x) * L.inv32.x, float(o.y) * L.inv32.y, float(o.z) * L.inv32.z};
 #if RTK_SIGNED_SLAB
+    if constexpr (!CH)  // (centre / half-extent boxes carry the origin's share of the error themselves: no bracket)
     // The origin's share of the float error travels with the RAY: o/d is bracketed, oi32_lo <= o/d <= oi32 -- the float
     // product is off by < 2^-21.9 relative (float(o) 2^-24, v_rcp_f32 1 ulp on float(d) 2^-24, the product 2^-24), and the
     // slab test's own final rounding adds 2^-24 of it -- so the boxes only have to carry their OWN share, 2^-21 of their own
@@ -497,7 +498,7 @@ RTK_DEV void begin_culling32(Lane<real>& L, V3<real> o, V3<real> d, float extent
 }
 
 // world.hit(r, interval(0.001, inf), rec) (Camera.txt:211) starts here.
-template <bool XF, bool MIXED = false, typename real, bool COUNT>
+template <bool XF, bool MIXED = false, bool CH = false, typename real, bool COUNT>
 RTK_DEV void begin_segment(Lane<real>& L, Counters<COUNT>& cnt, float extent = 0.0f) {
     cnt.inc(C_SEGMENTS);
     L.segs += 1;
@@ -510,7 +511,7 @@ RTK_DEV void begin_segment(Lane<real>& L, Counters<COUNT>& cnt, float extent = 0
     L.tmin = real(0.001);
     L.best_t = real_inf<real>();
     if constexpr (MIXED) {
-        begin_culling32(L, L.ro, L.rd, extent);
+        begin_culling32<CH>(L, L.ro, L.rd, extent);
         sync_interval32(L);
     } else {
         L.inv = mk(real(1) / L.rd.x, real(1) / L.rd.y, real(1) / L.rd.z);
@@ -633,13 +634,39 @@ RTK_DEV void step_box32(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cn
     L.pc = hit ? L.pc + UNITS : rec.aux;
 }
 #endif
+// RTK_CH_BOX (MIXED program): the box as centre c = f[0..2] and half-extent h = f[3..5]; per axis
+// tc = c/d - o/d, near = tc - h/|d|, far = tc + h/|d| -- which plane is the near one never has to be asked.  The
+// half-extent was grown for exactly this arithmetic (rtk_api.cpp build_mixed_program), so the test is conservative.
+RTK_DEV bool slab_test32_ch(const MixedHead& b, V3<float> oi, V3<float> inv, float tmin, float tmax) {
+    const float tcx = __builtin_fmaf(b.f(0), inv.x, -oi.x), tcy = __builtin_fmaf(b.f(1), inv.y, -oi.y), tcz = __builtin_fmaf(b.f(2), inv.z, -oi.z);
+    const float ax = __builtin_fabsf(inv.x), ay = __builtin_fabsf(inv.y), az = __builtin_fabsf(inv.z);  // source modifiers, no instructions
+    const float nx = __builtin_fmaf(-b.f(3), ax, tcx), fx = __builtin_fmaf(b.f(3), ax, tcx);
+    const float ny = __builtin_fmaf(-b.f(4), ay, tcy), fy = __builtin_fmaf(b.f(4), ay, tcy);
+    const float nz = __builtin_fmaf(-b.f(5), az, tcz), fz = __builtin_fmaf(b.f(5), az, tcz);
+    const float near = raw_max(raw_max3(nx, ny, nz), tmin);
+    const float far = raw_min(raw_min3(fx, fy, fz), tmax);
+    return far >= near;
+}
+template <typename real, bool COUNT>
+RTK_DEV void step_box32_ch(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cnt) {
+    cnt.inc(C_BOX);
+    const bool hit = slab_test32_ch(rec, L.oi32, L.inv32, L.tmin32, L.tmax32);
+    L.pc = hit ? L.pc + 1u : rec.aux;
+}
 // A box of those programs for a ray the float test must not judge (zero / out-of-range direction component, origin
 // outside the sized bound): aabb::hit's literal form in f64 on the (outward-rounded, hence still enclosing) bounds.
 template <bool XF = false, uint32_t UNITS = 1, typename real, bool COUNT>
 RTK_DEV void step_box_mixed_exact(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cnt) {
     cnt.inc(C_BOX);
     Slot<real> b;
-    for (int k = 0; k < 6; k++) b.v[k] = real(rec.f(k));
+    if constexpr (RTK_CH_BOX && UNITS == 1) {  // the MIXED program's centre / half-extent records
+        for (int k = 0; k < 3; k++) {
+            b.v[2 * k] = real(rec.f(k)) - real(rec.f(3 + k));
+            b.v[2 * k + 1] = real(rec.f(k)) + real(rec.f(3 + k));
+        }
+    } else {
+        for (int k = 0; k < 6; k++) b.v[k] = real(rec.f(k));
+    }
     const V3<real> d = ray_d<XF>(L);
     const V3<real> inv = mk(real(1) / d.x, real(1) / d.y, real(1) / d.z);
     const bool hit = slab_test<true>(b, ray_o<XF>(L), inv, L.tmin, L.best_t);
@@ -1037,6 +1064,13 @@ RTK_DEV void begin_sample(Lane<real>& L, const CameraRec<real>& cam, int i, int 
     L.depth = cam.max_depth;
 }
 
+// Kernels without point lights and emissive materials: a path gathers radiance only at the miss that ends it, so
+// `radiance` is +0 until then and `pixel_color += radiance` (Camera.txt:72) adds either +0 (sum + 0 == sum: the sum is
+// never -0) or 0 + throughput * background == throughput * background.  Those kernels keep no radiance registers
+// (lean MIXED kernel: 119 -> 113 VGPRs, C2 20.95 -> 20.84 ms, same framebuffer).
+template <uint32_t FEAT>
+constexpr bool kNoRadianceState = (FEAT & (F_LIGHTS | F_EXOTIC_MAT)) == 0;
+
 // The traversal program ran to OP_END: the body of ray_color after world.hit
 // (Camera.txt:211-237), iteratively (radiance = sum of throughput * emission).
 // Returns true when the sample's path has ended.
@@ -1046,7 +1080,8 @@ RTK_DEV bool shade(Lane<real>& L, const ProgT* __restrict__ hit_rec, const Scene
                    const CameraRec<real>& cam, Counters<COUNT>& cnt RTK_SHADE_PROF_PARAM) {
     RTK_SHADE_PROF_BEGIN
     if (L.best_pc == kNoHit) {  // Camera.txt:211-213
-        L.radiance = L.radiance + L.throughput * ld3(cam.background);
+        if constexpr (kNoRadianceState<FEAT>) L.sum = L.sum + L.throughput * ld3(cam.background);  // = sum + (0 + throughput * background), the same bits
+        else L.radiance = L.radiance + L.throughput * ld3(cam.background);
         return true;
     }
     cnt.inc(C_SURFACE);
@@ -1310,6 +1345,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
     // program (COLD): the whole "hot" program -- f32 culling boxes, spheres, every rare record -- in which each run of quads
     // or triangles is ONE two-unit record {kind, count, first unit in the cold array}; the quads and triangles themselves
     // ("cold": 144 / 80 bytes each, tested a few times per sample) stay in memory (SceneView::program_cold).
+    constexpr bool CH = RTK_CH_BOX && MIXED && !COMPACT;  // the MIXED program's boxes are centre / half-extent records
     constexpr bool SPLIT = LDS_PART && !COMPACT;
     constexpr bool COLD = LDS_PART && COMPACT;
     static_assert(!LDS_PART || !MIXED || COMPACT, "F_LDS_BOXES with f32 boxes: the COMPACT program");
@@ -1592,7 +1628,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                 cost_tile = it_cost_tile;
                 RTK_PROF_CHUNK_BEGIN
                 begin_sample(L, cam, px_i, px_j, seed_hash, cnt);
-                if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0, MIXED>(L, cnt, extent);
+                if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0, MIXED, CH>(L, cnt, extent);
                 else L.pc = end_pc;  // max_depth == 0: ray_color returns black at once (Camera.txt:205-206)
                 L.kind = kind_of(L.pc);
             }
@@ -1713,7 +1749,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             int remaining;
             [[maybe_unused]] SignMasks signs;
 #if RTK_SIGNED_SLAB
-            if constexpr (MIXED) {  // per-lane direction signs as wave masks; rays do not change inside this loop
+            if constexpr (MIXED && !CH) {  // per-lane direction signs as wave masks; rays do not change inside this loop
                 signs.x = __ballot(L.inv32.x < 0.0f);
                 signs.y = __ballot(L.inv32.y < 0.0f);
                 signs.z = __ballot(L.inv32.z < 0.0f);
@@ -1728,7 +1764,8 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             // also keeps the loop populated for longer.
             do {
                 if (k == box_kind) {
-                    if constexpr (MIXED) step_box32<kBoxUnits>(L, cur, cnt, signs);
+                    if constexpr (CH) step_box32_ch(L, cur, cnt);
+                    else if constexpr (MIXED) step_box32<kBoxUnits>(L, cur, cnt, signs);
                     else step_box<false, XF, (FEAT & F_FMA_BOX) != 0>(L, cur, cnt);
                     fetch();
                     L.kind = k;
@@ -1738,7 +1775,8 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                     // further box steps before the loop's scalar checks (vote / sphere / exit): the checks are a
                     // dependent v_cmp -> s_bcnt1 -> s_cmp -> branch chain per step, and the kernel is latency-bound
                     if (k == box_kind) {
-                        if constexpr (MIXED) step_box32<kBoxUnits>(L, cur, cnt, signs);
+                        if constexpr (CH) step_box32_ch(L, cur, cnt);
+                    else if constexpr (MIXED) step_box32<kBoxUnits>(L, cur, cnt, signs);
                         else step_box<false, XF, (FEAT & F_FMA_BOX) != 0>(L, cur, cnt);
                         fetch();
                         L.kind = k;
@@ -1891,7 +1929,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                 alive = true;
                 const bool ended = L.depth <= 0 || shade<real, FEAT, COUNT>(L, record_of(L.best_pc), sc, mats, cam, cnt RTK_SHADE_PROF_ARG);
                 if (ended) {  // pixel_color += ray_color(...) (Camera.txt:72)
-                    L.sum = L.sum + L.radiance;
+                    if constexpr (!kNoRadianceState<FEAT>) L.sum = L.sum + L.radiance;
                     L.s += 1;
                     if (L.s < s_end) {
                         next_sample = true;
@@ -1940,7 +1978,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             if (next_sample) begin_sample(L, cam, px_i, px_j, seed_hash, cnt);
             RTK_PROF_MARK(6, 1, popcount64(__ballot(next_sample)))
             if (alive) {
-                if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0, MIXED>(L, cnt, extent);
+                if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0, MIXED, CH>(L, cnt, extent);
                 else L.pc = end_pc;
                 L.kind = kind_of(L.pc);
             }

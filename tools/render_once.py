@@ -37,3 +37,5 @@ for k in range(launches):
     e1.synchronize()
     ms = e0.elapsed_time(e1)
     print(f"launch {k}: {ms:.3f} ms  {W*H*cam.samples_per_pixel/ms/1e3:.1f} Msamples/s  kernel={r.kernel_name(real, variant)}", flush=True)
+import hashlib
+print("framebuffer sha256", hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest()[:16], flush=True)

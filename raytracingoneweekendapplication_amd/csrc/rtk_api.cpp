@@ -382,7 +382,7 @@ static void build_mixed_program(const rtk_scene_desc& sc, const Program& prog, d
             rec->set_f(2, round_down(b.ymin - m)); rec->set_f(3, round_up(b.ymax + m));
             rec->set_f(4, round_down(b.zmin - m)); rec->set_f(5, round_up(b.zmax + m));
 #endif
-            rec->aux = unit_of_op[op.aux];
+            rec->aux = unit_of_op[op.aux] * ((RTK_CH_BOX && RTK_CH_BYTE_PC) ? uint32_t(sizeof(MixedHead)) : 1u);  // RTK_CH_BOX: the kernel's pcs count bytes
         } else if (kind == OP_SPHERE || kind == OP_SPHERE_MOVING) {
             const rtk_sphere& s = sc.spheres[payload];
             rec->set_d(0, s.center0.x); rec->set_d(1, s.center0.y); rec->set_d(2, s.center0.z);

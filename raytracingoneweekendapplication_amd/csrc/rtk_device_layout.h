@@ -44,6 +44,11 @@
 #define RTK_CH_BOX 1
 #endif
 
+// ... and (RTK_CH_BYTE_PC) that kernel's program counters and box links count bytes instead of 32-byte units
+#ifndef RTK_CH_BYTE_PC
+#define RTK_CH_BYTE_PC 1
+#endif
+
 namespace rtk {
 
 enum OpKind : uint32_t {

@@ -529,8 +529,10 @@ struct TieCtx {
     static constexpr bool enabled = TIE;
     const uint32_t* ranks;
     KindOf kind_of;
-    RTK_DEV bool sphere_wins(uint32_t pc, uint32_t best_pc) const { return tie_sphere_wins(ranks, pc, best_pc, best_pc == kNoHit ? 0u : kind_of(best_pc)); }
-    RTK_DEV bool inclusive_wins(uint32_t pc, uint32_t best_pc) const { return tie_inclusive_wins(ranks, pc, best_pc, best_pc == kNoHit ? 0u : kind_of(best_pc)); }
+    uint32_t shift = 0;  // a pc is (rank index << shift): 5 in the lean MIXED kernel, whose pcs count bytes
+    RTK_DEV uint32_t at(uint32_t pc) const { return pc == kNoHit ? kNoHit : pc >> shift; }
+    RTK_DEV bool sphere_wins(uint32_t pc, uint32_t best_pc) const { return tie_sphere_wins(ranks, at(pc), at(best_pc), best_pc == kNoHit ? 0u : kind_of(best_pc)); }
+    RTK_DEV bool inclusive_wins(uint32_t pc, uint32_t best_pc) const { return tie_inclusive_wins(ranks, at(pc), at(best_pc), best_pc == kNoHit ? 0u : kind_of(best_pc)); }
 };
 struct NoTie {
     static constexpr bool enabled = false;
@@ -634,6 +636,9 @@ RTK_DEV void step_box32(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cn
     L.pc = hit ? L.pc + UNITS : rec.aux;
 }
 #endif
+// The lean MIXED kernel's program counters count BYTES (a unit is 32 of them) when its boxes are centre / half-extent
+// records: the box step then needs no shift to turn its pc into an LDS address -- box step 19 -> 18 instructions.
+constexpr uint32_t kChPcUnit = RTK_CH_BYTE_PC ? 32u : 1u;
 // RTK_CH_BOX (MIXED program): the box as centre c = f[0..2] and half-extent h = f[3..5]; per axis
 // tc = c/d - o/d, near = tc - h/|d|, far = tc + h/|d| -- which plane is the near one never has to be asked.  The
 // half-extent was grown for exactly this arithmetic (rtk_api.cpp build_mixed_program), so the test is conservative.
@@ -651,11 +656,11 @@ template <typename real, bool COUNT>
 RTK_DEV void step_box32_ch(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cnt) {
     cnt.inc(C_BOX);
     const bool hit = slab_test32_ch(rec, L.oi32, L.inv32, L.tmin32, L.tmax32);
-    L.pc = hit ? L.pc + 1u : rec.aux;
+    L.pc = hit ? L.pc + kChPcUnit : rec.aux;  // (pcs of this kernel count bytes, and so does the link)
 }
 // A box of those programs for a ray the float test must not judge (zero / out-of-range direction component, origin
 // outside the sized bound): aabb::hit's literal form in f64 on the (outward-rounded, hence still enclosing) bounds.
-template <bool XF = false, uint32_t UNITS = 1, typename real, bool COUNT>
+template <bool XF = false, uint32_t UNITS = 1, uint32_t PCU = 1, typename real, bool COUNT>
 RTK_DEV void step_box_mixed_exact(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cnt) {
     cnt.inc(C_BOX);
     Slot<real> b;
@@ -670,13 +675,13 @@ RTK_DEV void step_box_mixed_exact(Lane<real>& L, const MixedHead& rec, Counters<
     const V3<real> d = ray_d<XF>(L);
     const V3<real> inv = mk(real(1) / d.x, real(1) / d.y, real(1) / d.z);
     const bool hit = slab_test<true>(b, ray_o<XF>(L), inv, L.tmin, L.best_t);
-    L.pc = hit ? L.pc + UNITS : rec.aux;
+    L.pc = hit ? L.pc + UNITS * PCU : rec.aux;
 }
 // sphere::hit on a MIXED record: centre in the head unit, radius in the next one.
-template <typename real, bool COUNT, typename Tie>
+template <uint32_t PCU = 1, typename real, bool COUNT, typename Tie>
 RTK_DEV void step_sphere_mixed(Lane<real>& L, const MixedHead& head, const MixedHead* __restrict__ rec, Counters<COUNT>& cnt, const Tie& tie) {
     const double radius = reinterpret_cast<const double*>(rec + 1)[0];
-    hit_sphere<false, true>(L, mk(real(head.d(0)), real(head.d(1)), real(head.d(2))), real(radius), 2u, cnt, tie);
+    hit_sphere<false, true>(L, mk(real(head.d(0)), real(head.d(1)), real(head.d(2))), real(radius), 2u * PCU, cnt, tie);
 }
 // ... and on a COMPACT record (3 units): the head (centre) is usually in registers already, the radius follows it.
 template <bool XF, typename real, bool COUNT, typename Tie>
@@ -684,17 +689,17 @@ RTK_DEV void step_sphere_compact(Lane<real>& L, const MixedHead& head, const Uni
     hit_sphere<XF, true>(L, mk(real(head.d(0)), real(head.d(1)), real(head.d(2))), packed<real, 3>(rec), 3u, cnt, tie);
 }
 // The remaining record kinds of a sphere-only program: a moving sphere, or a box for an irregular ray.
-template <typename real, bool COUNT, typename Tie>
+template <uint32_t PCU = 1, typename real, bool COUNT, typename Tie>
 RTK_DEV void step_other_mixed(Lane<real>& L, const MixedHead* __restrict__ rec, Counters<COUNT>& cnt, const Tie& tie) {
     const uint32_t kind = rec->kind_payload & 15u;
     if (kind == OP_BOX) {
-        step_box_mixed_exact(L, *rec, cnt);
+        step_box_mixed_exact<false, 1, PCU>(L, *rec, cnt);
     } else if (kind == OP_SPHERE_MOVING) {
         const double* cont = reinterpret_cast<const double*>(rec + 1);
         const V3<real> cc = mk(real(rec->d(0)), real(rec->d(1)), real(rec->d(2))) + scale(L.tm, mk(real(cont[2]), real(cont[3]), real(cont[4])));
-        hit_sphere<false, true>(L, cc, real(cont[0]), 3u, cnt, tie);
+        hit_sphere<false, true>(L, cc, real(cont[0]), 3u * PCU, cnt, tie);
     } else {
-        L.pc += uint32_t(mixed_units(kind));  // unreachable for a validated sphere-only program
+        L.pc += uint32_t(mixed_units(kind)) * PCU;  // unreachable for a validated sphere-only program
     }
 }
 // bvh_node::hit's box test (bvh.h:65): on a miss skip the whole subtree.
@@ -1331,6 +1336,14 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                                                           unsigned int* __restrict__ tile_counter, const int32_t* __restrict__ tile_order,
                                                           unsigned int* __restrict__ tile_cost, uint32_t diag) {
     extern __shared__ __align__(16) unsigned char lds_program[];
+#ifndef RTK_CH_LDS_ABS
+#define RTK_CH_LDS_ABS 1
+#endif
+    if constexpr (RTK_CH_BOX && RTK_CH_BYTE_PC && RTK_CH_LDS_ABS && IN_LDS) {
+        // (lean MIXED kernel: byte pcs are used as LDS addresses, see rec_at) -- render nothing rather than garbage otherwise
+        typedef const unsigned char __attribute__((address_space(3))) * lds_bytes_t;
+        if (uint32_t(size_t((lds_bytes_t)lds_program)) != 0u) return;
+    }
 #ifndef RTK_DEV_MASK_OFF
 #define RTK_DEV_MASK_OFF 0u   // register-pressure experiments (tools/kernel_resources.py): feature bits compiled out of every kernel
 #endif
@@ -1427,15 +1440,27 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
     // the head of the record that starts at pc, as a step holds it in registers
     // (COLD: a lane inside a run of cold primitives keeps its position in the run in the top byte of its pc)
     constexpr uint32_t kPcMask = COLD ? 0x00FFFFFFu : 0xFFFFFFFFu;
+    constexpr uint32_t kPcUnit = CH ? kChPcUnit : 1u;  // what one unit of the program adds to a pc (CH: pcs count bytes)
+    // the record that starts at pc
+    auto rec_at = [&](uint32_t pc) -> const ProgRec* {
+        if constexpr (CH && RTK_CH_BYTE_PC && IN_LDS && RTK_CH_LDS_ABS) {
+            // The staged program starts at LDS address 0 -- this kernel declares no static LDS, so its dynamic segment does
+            // (checked when the kernel starts, and on the code object by tests/test_abi_and_host.py) -- hence a byte pc IS
+            // the LDS address: the box step's next read needs no address arithmetic at all (C2 19.35 -> 18.96 ms).
+            typedef const unsigned char __attribute__((address_space(3))) * lds_bytes_t;
+            return reinterpret_cast<const ProgRec*>((const unsigned char*)(lds_bytes_t)(size_t)pc);
+        } else if constexpr (CH && RTK_CH_BYTE_PC) return reinterpret_cast<const ProgRec*>(reinterpret_cast<const unsigned char*>(prog) + pc);
+        else return prog + pc;
+    };
     auto head_at = [&](uint32_t pc) -> CurRec {
         if constexpr (COMPACT) return *reinterpret_cast<const MixedHead*>(prog + (pc & kPcMask));
-        else return prog[pc];
+        else return *rec_at(pc);
     };
     // kind of the record that starts at pc; the box record at pc (SPLIT: from the LDS copies)
     auto kind_of = [&](uint32_t pc) -> uint32_t {
         if constexpr (SPLIT) return (lds_kinds[pc >> 3] >> ((pc & 7u) * 4u)) & 15u;
         else if constexpr (COMPACT) return prog[(pc & kPcMask) + 1].w[2] & 15u;
-        else return prog[pc].kind_payload & 15u;
+        else return rec_at(pc)->kind_payload & 15u;
     };
     [[maybe_unused]] auto box_at = [&](uint32_t pc) -> CurRec {
         const uint2 e = lds_rank[pc >> 5];
@@ -1455,7 +1480,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
     // The record a closest hit names (L.best_pc): a pc of the program, or -- COLD -- n_records + the unit of a cold primitive.
     auto record_of = [&](uint32_t id) -> const ProgRec* {
         if constexpr (COLD) return id < uint32_t(n_records) ? prog + id : reinterpret_cast<const ProgRec*>(cold + (id - uint32_t(n_records)));
-        else return prog + id;
+        else return rec_at(id);
     };
     [[maybe_unused]] auto kind_of_hit = [&](uint32_t id) -> uint32_t {  // for the tie rule: the kind of the current winner
         if constexpr (COLD) return id < uint32_t(n_records) ? kind_of(id) : (cold[id - uint32_t(n_records) + 1].w[2] & 15u);
@@ -1485,7 +1510,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
 #define RTK_AB_NO_TIE 0   // tools/ab: what the tie rule costs
 #endif
     constexpr bool TIE = !RTK_AB_NO_TIE && sizeof(real) == 8 && ((FEAT & (F_FMA_BOX | F_F32_BOX)) != 0 || (FEAT & ~uint32_t(F_MATTE)) == kFeatQuadBox);
-    const TieCtx<TIE, decltype(kind_of_hit)> tie{TIE ? (COLD ? sc.tie_rank_hot : (MIXED ? sc.tie_rank : sc.tie_rank_slot)) : nullptr, kind_of_hit};
+    const TieCtx<TIE, decltype(kind_of_hit)> tie{TIE ? (COLD ? sc.tie_rank_hot : (MIXED ? sc.tie_rank : sc.tie_rank_slot)) : nullptr, kind_of_hit, (CH && RTK_CH_BYTE_PC) ? 5u : 0u};
     // The hand-out order of the tiles (learned from the previous frame) is staged behind the program when the host
     // found room for it (tmap.order_in_lds): a lookup per work item from LDS instead of a cold global load.
     if constexpr ((FEAT & F_XFORM) != 0 && (IN_LDS || LDS_PART)) {
@@ -1513,7 +1538,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
     const uint32_t seed_hash = pcg_hash(seed);
     const int n_tiles_total = tmap.tiles_x * tmap.tiles_y;
     const int width = cam.width, height = cam.height, spp = cam.spp;
-    const uint32_t end_pc = uint32_t(n_records - (COMPACT ? 2 : 1));  // OP_END: the last record (two units in the COMPACT layout)
+    const uint32_t end_pc = uint32_t(n_records - (COMPACT ? 2 : 1)) * kPcUnit;  // OP_END: the last record (two units in the COMPACT layout)
     const float extent = sc.extent;
     Counters<COUNT> cnt;
     cnt.clear();
@@ -1737,7 +1762,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                     if (k == OP_BOX) cur = box_at(L.pc);
                 } else {
                     cur = head_at(L.pc);
-                    k = cur.kind_payload & 15u;
+                    k = cur.kind_payload & 15u;  // (a header word that IS the kind, read without the mask: the allocator answers with 14 moves per step, 21.9 vs 19.4 ms)
                 }
             };
             if constexpr (SPLIT) {
@@ -1786,7 +1811,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                     if (k == OP_SPHERE) {
                         if constexpr (SPLIT) cur = head_at(L.pc);
                         if constexpr (COMPACT) step_sphere_compact<XF>(L, cur, prog + L.pc, cnt, tie);
-                        else if constexpr (MIXED) step_sphere_mixed(L, cur, prog + L.pc, cnt, tie);
+                        else if constexpr (MIXED) step_sphere_mixed<kPcUnit>(L, cur, rec_at(L.pc), cnt, tie);
                         else step_sphere<XF>(L, cur, cnt, tie);
                         fetch();
                         L.kind = k;
@@ -1849,7 +1874,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             do {
                 if (k == OP_SPHERE) {
                     if constexpr (COMPACT) step_sphere_compact<XF>(L, cur, prog + L.pc, cnt, tie);
-                    else if constexpr (MIXED) step_sphere_mixed(L, cur, prog + L.pc, cnt, tie);
+                    else if constexpr (MIXED) step_sphere_mixed<kPcUnit>(L, cur, rec_at(L.pc), cnt, tie);
                     else step_sphere<XF>(L, cur, cnt, tie);
                     if constexpr (SPLIT) {
                         k = kind_of(L.pc);
@@ -1988,7 +2013,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             RTK_PROF_MARK(7, 1, popcount64(__ballot(alive)))
         } else {
             if (m_oth >> lane & 1ull) {
-                if constexpr (MIXED && !COMPACT) step_other_mixed(L, prog + L.pc, cnt, tie);
+                if constexpr (MIXED && !COMPACT) step_other_mixed<kPcUnit>(L, rec_at(L.pc), cnt, tie);
                 else step_other<real, FEAT, COUNT>(L, prog + L.pc, sc, cnt, tie, extent);
                 L.kind = kind_of(L.pc);
             }

@@ -33,6 +33,35 @@ def test_kernels_are_built_for_gfx950_only(rt):
         assert other not in blob
 
 
+def test_render_kernels_declare_no_static_lds(rt, tmp_path):
+    """The lean MIXED kernel uses its byte program counters as LDS addresses (rtk_trace.hip rec_at): the staged program must
+    start at LDS address 0, i.e. the kernels' static LDS size in the code object's metadata must be 0."""
+    import shutil
+    import subprocess
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm LLVM binary tools not present")
+    fat, dev = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    subprocess.check_call([tools[0], f"--dump-section=.hip_fatbin={fat}", rt.HIP_LIB_PATH, str(tmp_path / "copy.so")])
+    subprocess.check_call([tools[1], "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={dev}", "--unbundle"])
+    notes = subprocess.check_output([tools[2], "--notes", dev], text=True)
+    sizes = {}
+    fixed = None
+    for line in notes.splitlines():
+        m = re.search(r"\.group_segment_fixed_size:\s*(\d+)", line)
+        if m:
+            fixed = int(m.group(1))
+        m = re.search(r"\.name:\s*(\S+)", line)
+        if m and fixed is not None:
+            sizes[m.group(1)] = fixed
+            fixed = None
+    render = {k: v for k, v in sizes.items() if "rtk_render_kernel" in k}
+    assert len(render) >= 20, sorted(sizes)[:5]
+    assert all(v == 0 for v in render.values()), {k: v for k, v in render.items() if v}
+
+
 def test_product_fails_loudly_without_a_device(rt):
     import torch
 

@@ -169,6 +169,7 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-f32", action="store_true")
     p.add_argument("--no-other-order", action="store_true", help="skip the untimed render in the other visiting order (profiling runs)")
+    p.add_argument("--no-other-configs", action="store_true", help="skip the short measurements of the other BASELINE configs (N = 1, default config only)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     p.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2],
                    help="2: frames alternate between two contexts and streams, so the end of one frame overlaps the start of the next; "
@@ -449,6 +450,39 @@ def main():
             f32_mode = {"value": round(samples_per_step * max(1, min(args.steps, 3)) / e32 / 1e6, 2), "unit": "Msamples/s", "kernel_ms": round(k32, 4),
                         "note": "throughput mode; parity vs the double reference is statistical only (SURVEY.md 8(d)); not the headline"}
 
+    # ---- the other BASELINE configs (parity-test cases, not the headline): a few frames each at full size, in the order and
+    # with the kernel `--config cN` would time, so that their rates are on the driver's record too.  N = 1, default config only.
+    other_configs = None
+    if rank == 0 and n == 1 and args.config == "c2" and not reduced and not args.variant and not args.no_other_configs:
+        other_configs = {}
+        for cfg in ("c3", "c4", "c5"):
+            try:
+                name_ = rt.CONFIG_SCENES[cfg]
+                scene_ = rt.Scene.build(name_, rt.SCENE_SEED, earth)
+                cam_ = scene_.camera(0, 0, 0, 0)
+                fast_ = scene_.fast_order(cam_.center)
+                r_ = rt.Renderer(local_rank)
+                r_.upload_fast(scene_, cam_.center) if fast_.exact else r_.upload(scene_)
+                W_, H_, spp_ = cam_.image_width, cam_.image_height, cam_.samples_per_pixel
+                img_ = torch.empty((H_, W_, 3), dtype=torch.float64, device=dev)
+                u8_ = torch.empty((H_, W_, 3), dtype=torch.uint8, device=dev)
+                frames = 2 if cfg == "c5" else 3
+                r_.render_device(cam_, img_.data_ptr(), u8_.data_ptr(), real_mode=rt.RTK_REAL_F64, stream=stream)  # untimed: learns the tile order
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(frames):
+                    r_.render_device(cam_, img_.data_ptr(), u8_.data_ptr(), real_mode=rt.RTK_REAL_F64, stream=stream)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                other_configs[cfg] = {"workload": f"{name_} {W_}x{H_}x{spp_}spp depth {cam_.max_depth}" + WORKLOAD_NOTES.get(cfg, ""),
+                                      "value": round(W_ * H_ * spp_ * frames / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt / frames * 1e3, 3),
+                                      "steps": frames, "dtype": "f64", "order": "fast (rtk_scene_upload_fast)" if fast_.exact else "reference (bvh.h)",
+                                      "kernel": r_.kernel_name(rt.RTK_REAL_F64, 0),
+                                      "framebuffer_sha256": hashlib.sha256(img_.cpu().numpy().tobytes()).hexdigest()[:16]}
+                del r_, img_, u8_, scene_
+            except Exception as exc:  # reported, never required
+                other_configs[cfg] = {"value": None, "error": str(exc)}
+
     cpu = None
     if rank == 0 and n == 1 and not args.no_cpu_baseline:
         try:
@@ -470,6 +504,7 @@ def main():
             "cpu_baseline": cpu,
             "f32_mode": f32_mode,
             "other_order": other,
+            "other_configs": other_configs,
             "speedup_vs_cpu_baseline": (round(value / cpu["value"], 1) if cpu and cpu.get("value") else None),
             "framebuffer_sha256": checksum,
         }

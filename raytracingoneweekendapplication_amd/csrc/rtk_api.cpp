@@ -437,8 +437,14 @@ static double scene_extent(const rtk_scene_desc& sc, double eye_extent) {
 // [-extent, extent]^3 through the exact test), every primitive in f64, 16-byte units.
 // One record of the COMPACT layout for op i (kind = its kind with moving spheres told apart) at `dst`; links (a box's or
 // a MED_MID's `aux`) are translated through `unit_of_link`.
+// COMPACT programs of the mesh family hold centre / half-extent box records (the rule of rtk_trace.hip kCompactChStatic)
+static bool compact_ch_family(const Program& prog) {
+    const uint32_t scene = prog.features & ~uint32_t(F_FMA_BOX | F_MATTE);
+    return RTK_CH_COMPACT && scene != kFeatLean && (scene & ~kFeatQuadBox) != 0 && (scene & ~kFeatMesh) == 0;
+}
+
 static void write_compact_record(const rtk_scene_desc& sc, const Program& prog, size_t i, uint32_t kind, Unit16* dst, double margin,
-                                 const std::vector<uint32_t>& unit_of_link) {
+                                 const std::vector<uint32_t>& unit_of_link, bool ch_boxes = false) {
     const Op& op = prog.ops[i];
     const uint32_t payload = op.kind_payload >> 4;
     MixedHead* head = reinterpret_cast<MixedHead*>(dst);
@@ -449,10 +455,25 @@ static void write_compact_record(const rtk_scene_desc& sc, const Program& prog, 
     switch (kind) {
         case OP_BOX: {
             const rtk_aabb& b = sc.bvh_boxes[payload];
+            if (ch_boxes) {
+            // centre / half-extent form, as in build_mixed_program, except that the origin's share of the error ((2.5 + 1) 2^-23
+            // |o / d|) is not the box's to carry: the ray does (slab_test32_che's slack, 2^-20 max |o / d|), so that a box grows
+            // by 2^-21 of its OWN coordinates whatever the scene's extent (the Cornell quads' boxes are 1e-4 thick, at 555)
+            const double lo[3] = {b.xmin, b.ymin, b.zmin}, hi[3] = {b.xmax, b.ymax, b.zmax};
+            for (int ax = 0; ax < 3; ax++) {
+                const double c = 0.5 * (lo[ax] + hi[ax]);
+                const float cf = float(c);
+                const double h = std::max(hi[ax] - double(cf), double(cf) - lo[ax]);
+                const double grown = h + std::ldexp(std::fabs(double(cf)) + h, -21) + 1e-300;
+                head->set_f(ax, cf);
+                head->set_f(3 + ax, round_up(grown * (1.0 + 1e-7)));
+            }
+            } else {
             const double m = box_margin(b, margin);
             head->set_f(0, round_down(b.xmin - m)); head->set_f(1, round_up(b.xmax + m));
             head->set_f(2, round_down(b.ymin - m)); head->set_f(3, round_up(b.ymax + m));
             head->set_f(4, round_down(b.zmin - m)); head->set_f(5, round_up(b.zmax + m));
+            }
             head->aux = unit_of_link[op.aux];
             break;
         }
@@ -520,7 +541,7 @@ static void build_compact_program(const rtk_scene_desc& sc, const Program& prog,
     units.assign(unit_of_op.back(), Unit16{{0u, 0u, 0u, 0u}});
     rank_of_unit.assign(unit_of_op.back(), 0u);
     for (size_t i = 0; i < prog.ops.size(); i++) {
-        write_compact_record(sc, prog, i, compact_kind_of(sc, prog.ops[i]), &units[unit_of_op[i]], margin, unit_of_op);
+        write_compact_record(sc, prog, i, compact_kind_of(sc, prog.ops[i]), &units[unit_of_op[i]], margin, unit_of_op, compact_ch_family(prog));
         rank_of_unit[unit_of_op[i]] = prog.ranks[i];
     }
     extent_out = float(extent);
@@ -814,6 +835,7 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
     }
     out.view.program_compact = nullptr;
     out.view.n_units16 = 0;
+    out.view.compact_ch = 0;
     out.view.program_hot = nullptr;
     out.view.program_cold = nullptr;
     out.view.n_hot_units = out.view.n_cold_units = 0;
@@ -844,6 +866,7 @@ int build_device_scene(const rtk_scene_desc& sc, const Program& prog, DeviceScen
             if ((rc = out.upload(units, &out.view.program_compact)) != RTK_OK) return rc;
             if ((rc = out.upload(ranks, &out.view.tie_rank)) != RTK_OK) return rc;
             out.view.n_units16 = int32_t(units.size());
+            out.view.compact_ch = compact_ch_family(prog) ? 1 : 0;
             // the same program in its hot/cold form: for programs too large for LDS -- and, through variant bit 23, for tests
             // of that form on scenes small enough for the oracle (only the full-feature kernel family has it)
             if ((prog.features & ~kFeatQuadBox) != 0 && (prog.features & ~kFeatMesh) != 0) {

@@ -49,6 +49,14 @@
 #define RTK_CH_BYTE_PC 1
 #endif
 
+// COMPACT program: 1 = centre / half-extent records for the programs of the mesh family (triangles + spheres) as well; the
+// origin's share of the float error stays with the RAY, as one slack term for all three axes (rtk_trace.hip
+// slab_test32_che), so a box is grown by 2^-21 of its own coordinates only -- nine fused multiply-adds, a subtraction and a
+// compare against -2 x slack.  The other families keep the sign-selected test (measured, see rtk_trace.hip).
+#ifndef RTK_CH_COMPACT
+#define RTK_CH_COMPACT 1
+#endif
+
 namespace rtk {
 
 enum OpKind : uint32_t {
@@ -252,6 +260,7 @@ struct SceneView {  // device pointers, passed to the kernel by value
     // the reference order) -- same `extent` rule, applied to the object-space origin under instance transforms
     const Unit16* program_compact;
     int32_t n_units16;
+    int32_t compact_ch;  // 1 = program_compact's box records are centre / half-extent (RTK_CH_COMPACT: the mesh family's programs)
     // ... and, for COMPACT programs too large for LDS, the same program in two parts (F_LDS_BOXES | F_F32_BOX kernels): the
     // hot part -- staged in LDS -- holds every record except quads and triangles, with one two-unit record {kind, count;
     // aux = first unit in program_cold} per run of them; program_cold holds those primitives' usual records.  A hit on a

@@ -428,6 +428,7 @@ struct Lane {
     V3<float> oi32_lo;  // oi32 holds the UPPER bracket of o/d, this the lower one (see begin_culling32)
 #endif
     float tmin32, tmax32;
+    float m2slack32;         // COMPACT kernels with centre / half-extent boxes: -2 x the ray's slack (slab_test32_che)
     real a, inv_a, tm;       // d.d (sphere.h:35, hoisted likewise) and 1/(d.d) for divide_by; ray time
     real tmin, best_t;       // current query interval: (tmin, closest so far)
     real sv_tmin, sv_best_t, rec1_t;  // constant_medium::hit nests two closest-hit queries of its boundary
@@ -471,13 +472,19 @@ RTK_DEV void sync_interval32(Lane<real>& L) {
 // F_F32_BOX: 1/d and o/d in float for the culling boxes (one v_rcp_f32 per axis instead of an f64 division), and
 // whether the f32 test may be used at all: direction components neither zero nor beyond float range, origin inside
 // the coordinate bound the box margin was sized for (rtk_api.cpp build_mixed_program).
-template <bool CH = false, typename real>
+template <int CH = 0, typename real>
 RTK_DEV void begin_culling32(Lane<real>& L, V3<real> o, V3<real> d, float extent) {
     const V3<float> d32 = V3<float>{float(d.x), float(d.y), float(d.z)};
     L.inv32 = V3<float>{__builtin_amdgcn_rcpf(d32.x), __builtin_amdgcn_rcpf(d32.y), __builtin_amdgcn_rcpf(d32.z)};
     L.oi32 = V3<float>{float(o.x) * L.inv32.x, float(o.y) * L.inv32.y, float(o.z) * L.inv32.z};
 #if RTK_SIGNED_SLAB
-    if constexpr (!CH)  // (centre / half-extent boxes carry the origin's share of the error themselves: no bracket)
+    if constexpr (CH >= 2) {
+        // centre / half-extent boxes that carry only their own share: the origin's -- o/d off by < (2.5 + 1) 2^-23 |o/d| per
+        // axis, the two final roundings of the test included -- becomes ONE slack for all axes, 2^-20 of the largest |o/d|
+        const float big_oi = raw_max3(__builtin_fabsf(L.oi32.x), __builtin_fabsf(L.oi32.y), __builtin_fabsf(L.oi32.z));
+        L.m2slack32 = -2.0f * (big_oi * (CH == 3 ? 1.9073486e-06f : 9.5367432e-07f));  // (3: oi32 becomes the bracket's upper end below -- twice the slack covers that)
+    }
+    if constexpr (CH == 0 || CH == 3)  // (centre / half-extent boxes: no bracket; 3 = a counting kernel that serves both record forms)
     // The origin's share of the float error travels with the RAY: o/d is bracketed, oi32_lo <= o/d <= oi32 -- the float
     // product is off by < 2^-21.9 relative (float(o) 2^-24, v_rcp_f32 1 ulp on float(d) 2^-24, the product 2^-24), and the
     // slab test's own final rounding adds 2^-24 of it -- so the boxes only have to carry their OWN share, 2^-21 of their own
@@ -498,7 +505,7 @@ RTK_DEV void begin_culling32(Lane<real>& L, V3<real> o, V3<real> d, float extent
 }
 
 // world.hit(r, interval(0.001, inf), rec) (Camera.txt:211) starts here.
-template <bool XF, bool MIXED = false, bool CH = false, typename real, bool COUNT>
+template <bool XF, bool MIXED = false, int CH = 0, typename real, bool COUNT>
 RTK_DEV void begin_segment(Lane<real>& L, Counters<COUNT>& cnt, float extent = 0.0f) {
     cnt.inc(C_SEGMENTS);
     L.segs += 1;
@@ -652,6 +659,25 @@ RTK_DEV bool slab_test32_ch(const MixedHead& b, V3<float> oi, V3<float> inv, flo
     const float far = raw_min(raw_min3(fx, fy, fz), tmax);
     return far >= near;
 }
+// ... with the ray's slack (COMPACT programs): the planes may each be off by `slack` = -m2slack / 2 in t, so the box is
+// passed when min(far, tmax) - max(near, tmin) >= -2 slack -- at the interval's ends a touch more permissive than
+// clamping the widened planes, never less.
+RTK_DEV bool slab_test32_che(const MixedHead& b, V3<float> oi, V3<float> inv, float tmin, float tmax, float m2slack) {
+    const float tcx = __builtin_fmaf(b.f(0), inv.x, -oi.x), tcy = __builtin_fmaf(b.f(1), inv.y, -oi.y), tcz = __builtin_fmaf(b.f(2), inv.z, -oi.z);
+    const float ax = __builtin_fabsf(inv.x), ay = __builtin_fabsf(inv.y), az = __builtin_fabsf(inv.z);
+    const float nx = __builtin_fmaf(-b.f(3), ax, tcx), fx = __builtin_fmaf(b.f(3), ax, tcx);
+    const float ny = __builtin_fmaf(-b.f(4), ay, tcy), fy = __builtin_fmaf(b.f(4), ay, tcy);
+    const float nz = __builtin_fmaf(-b.f(5), az, tcz), fz = __builtin_fmaf(b.f(5), az, tcz);
+    const float near = raw_max(raw_max3(nx, ny, nz), tmin);
+    const float far = raw_min(raw_min3(fx, fy, fz), tmax);
+    return far - near >= m2slack;
+}
+template <typename real, bool COUNT>
+RTK_DEV void step_box32_che(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cnt) {
+    cnt.inc(C_BOX);
+    const bool hit = slab_test32_che(rec, L.oi32, L.inv32, L.tmin32, L.tmax32, L.m2slack32);
+    L.pc = hit ? L.pc + 2u : rec.aux;
+}
 template <typename real, bool COUNT>
 RTK_DEV void step_box32_ch(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cnt) {
     cnt.inc(C_BOX);
@@ -661,10 +687,10 @@ RTK_DEV void step_box32_ch(Lane<real>& L, const MixedHead& rec, Counters<COUNT>&
 // A box of those programs for a ray the float test must not judge (zero / out-of-range direction component, origin
 // outside the sized bound): aabb::hit's literal form in f64 on the (outward-rounded, hence still enclosing) bounds.
 template <bool XF = false, uint32_t UNITS = 1, uint32_t PCU = 1, typename real, bool COUNT>
-RTK_DEV void step_box_mixed_exact(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cnt) {
+RTK_DEV void step_box_mixed_exact(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cnt, bool compact_ch = false) {
     cnt.inc(C_BOX);
     Slot<real> b;
-    if constexpr (RTK_CH_BOX && UNITS == 1) {  // the MIXED program's centre / half-extent records
+    if ((RTK_CH_BOX && UNITS == 1) || (UNITS == 2 && compact_ch)) {  // centre / half-extent records (the MIXED program; COMPACT programs of the mesh family)
         for (int k = 0; k < 3; k++) {
             b.v[2 * k] = real(rec.f(k)) - real(rec.f(3 + k));
             b.v[2 * k + 1] = real(rec.f(k)) + real(rec.f(3 + k));
@@ -718,6 +744,18 @@ RTK_DEV void step_sphere(Lane<real>& L, const Slot<real>& rec, Counters<COUNT>& 
     hit_sphere<XF, false>(L, mk(rec.v[0], rec.v[1], rec.v[2]), rec.v[3], 1u, cnt, tie);
 }
 
+// Which COMPACT programs hold centre / half-extent box records (RTK_CH_COMPACT): those of the mesh family -- the same rule
+// in rtk_api.cpp, which also sets SceneView::compact_ch for the counting kernel, the one kernel that serves every family.
+// (Measured: C4 62.3 -> 59.7 ms; the Cornell box and book 2, thin axis-aligned quads at coordinates in the hundreds
+// and thousands, lose 2-4 % to the all-axes slack and keep the sign-selected test with its per-axis bracket.)
+template <uint32_t FEAT>
+constexpr bool kCompactChStatic = RTK_CH_COMPACT && (FEAT & F_F32_BOX) != 0 && (FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE | F_LDS_BOXES)) == kFeatMesh;
+template <uint32_t FEAT, bool COUNT, typename real>
+RTK_DEV bool compact_ch_records(const SceneView<real>& sc) {
+    if constexpr (kCompactChStatic<FEAT>) return true;
+    else if constexpr (RTK_CH_COMPACT && COUNT) return sc.compact_ch != 0;
+    else return false;
+}
 // Every other record kind (moving sphere, quad, triangle, chain switch, the three medium ops, a box met by a ray the
 // box loop does not take).  `rec` points at the record in the program (LDS or global), in the slot layout (Slot<real>)
 // or -- F_F32_BOX kernels of the non-lean families -- the COMPACT one (Unit16).
@@ -729,7 +767,7 @@ RTK_DEV void step_other(Lane<real>& L, const Rec* __restrict__ rec, const SceneV
     const uint32_t aux = rec_aux<real>(rec);
     const uint32_t kind = kp & 15u;
     if (kind == OP_BOX) {  // only for rays with a zero or infinite direction component: the literal, NaN-exact slab test
-        if constexpr (MIXED) step_box_mixed_exact<XF, 2>(L, *reinterpret_cast<const MixedHead*>(rec), cnt);
+        if constexpr (MIXED) step_box_mixed_exact<XF, 2>(L, *reinterpret_cast<const MixedHead*>(rec), cnt, compact_ch_records<FEAT, COUNT>(sc));
         else step_box<true, XF>(L, *reinterpret_cast<const Slot<real>*>(rec), cnt);
     } else if (kind == OP_SPHERE_MOVING) {
         const V3<real> cc = packed3<real, 0>(rec) + scale(L.tm, moving_dir<real>(rec));
@@ -744,7 +782,7 @@ RTK_DEV void step_other(Lane<real>& L, const Rec* __restrict__ rec, const SceneV
         L.a = length_squared(L.d);
         L.inv_a = real(1) / L.a;
         if constexpr (MIXED) {
-            begin_culling32(L, L.o, L.d, extent);  // 1/d, o/d in float for the boxes of this space; the interval (a ray parameter) is unchanged
+            begin_culling32(L, L.o, L.d, extent);  // (programs with instance chains keep the sign-selected test) 1/d, o/d in float for the boxes of this space; the interval (a ray parameter) is unchanged
         } else {
             L.inv = mk(real(1) / L.d.x, real(1) / L.d.y, real(1) / L.d.z);
             L.box_kind = regular_direction(L.inv) ? uint32_t(OP_BOX) : kIrregularBox;
@@ -1359,6 +1397,10 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
     // or triangles is ONE two-unit record {kind, count, first unit in the cold array}; the quads and triangles themselves
     // ("cold": 144 / 80 bytes each, tested a few times per sample) stay in memory (SceneView::program_cold).
     constexpr bool CH = RTK_CH_BOX && MIXED && !COMPACT;  // the MIXED program's boxes are centre / half-extent records
+    constexpr bool CHE = COMPACT && kCompactChStatic<FEAT>;  // ... and so are the COMPACT programs' of the mesh family, with a per-ray slack
+    constexpr bool CHE_RT = RTK_CH_COMPACT && COMPACT && COUNT && !CHE;  // the counting kernel on any family's COMPACT program: asks the scene
+    [[maybe_unused]] const bool che_rt = CHE_RT && sc.compact_ch != 0;
+    constexpr int kCulling = CH ? 1 : (CHE ? 2 : (CHE_RT ? 3 : 0));
     constexpr bool SPLIT = LDS_PART && !COMPACT;
     constexpr bool COLD = LDS_PART && COMPACT;
     static_assert(!LDS_PART || !MIXED || COMPACT, "F_LDS_BOXES with f32 boxes: the COMPACT program");
@@ -1653,7 +1695,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                 cost_tile = it_cost_tile;
                 RTK_PROF_CHUNK_BEGIN
                 begin_sample(L, cam, px_i, px_j, seed_hash, cnt);
-                if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0, MIXED, CH>(L, cnt, extent);
+                if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0, MIXED, kCulling>(L, cnt, extent);
                 else L.pc = end_pc;  // max_depth == 0: ray_color returns black at once (Camera.txt:205-206)
                 L.kind = kind_of(L.pc);
             }
@@ -1774,7 +1816,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             int remaining;
             [[maybe_unused]] SignMasks signs;
 #if RTK_SIGNED_SLAB
-            if constexpr (MIXED && !CH) {  // per-lane direction signs as wave masks; rays do not change inside this loop
+            if constexpr (MIXED && !CH && !CHE) {  // per-lane direction signs as wave masks; rays do not change inside this loop
                 signs.x = __ballot(L.inv32.x < 0.0f);
                 signs.y = __ballot(L.inv32.y < 0.0f);
                 signs.z = __ballot(L.inv32.z < 0.0f);
@@ -1790,6 +1832,11 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             do {
                 if (k == box_kind) {
                     if constexpr (CH) step_box32_ch(L, cur, cnt);
+                    else if constexpr (CHE) step_box32_che(L, cur, cnt);
+                    else if constexpr (CHE_RT) {
+                        if (che_rt) step_box32_che(L, cur, cnt);
+                        else step_box32<kBoxUnits>(L, cur, cnt, signs);
+                    }
                     else if constexpr (MIXED) step_box32<kBoxUnits>(L, cur, cnt, signs);
                     else step_box<false, XF, (FEAT & F_FMA_BOX) != 0>(L, cur, cnt);
                     fetch();
@@ -1801,6 +1848,11 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                     // dependent v_cmp -> s_bcnt1 -> s_cmp -> branch chain per step, and the kernel is latency-bound
                     if (k == box_kind) {
                         if constexpr (CH) step_box32_ch(L, cur, cnt);
+                    else if constexpr (CHE) step_box32_che(L, cur, cnt);
+                    else if constexpr (CHE_RT) {
+                        if (che_rt) step_box32_che(L, cur, cnt);
+                        else step_box32<kBoxUnits>(L, cur, cnt, signs);
+                    }
                     else if constexpr (MIXED) step_box32<kBoxUnits>(L, cur, cnt, signs);
                         else step_box<false, XF, (FEAT & F_FMA_BOX) != 0>(L, cur, cnt);
                         fetch();
@@ -2003,7 +2055,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             if (next_sample) begin_sample(L, cam, px_i, px_j, seed_hash, cnt);
             RTK_PROF_MARK(6, 1, popcount64(__ballot(next_sample)))
             if (alive) {
-                if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0, MIXED, CH>(L, cnt, extent);
+                if (L.depth > 0) begin_segment<(FEAT & F_XFORM) != 0, MIXED, kCulling>(L, cnt, extent);
                 else L.pc = end_pc;
                 L.kind = kind_of(L.pc);
             }

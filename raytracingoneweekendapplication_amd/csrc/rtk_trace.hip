@@ -135,12 +135,24 @@ RTK_DEV real rnd(uint32_t& s, Counters<COUNT>& cnt) {
     cnt.inc(C_RNG);
     return real(((w >> 22u) ^ w) >> 8) * real(1.0 / 16777216.0);
 }
+// random_double(-1, 1) = -1 + 2 * random_double() (rtweekend.h) of the next draw, without a rounding anywhere: a draw is
+// v * 2^-24 with v a 24-bit integer, so 2 * draw and -1 + 2 * draw are exact (multiples of 2^-23 in [-1, 1)), and the same
+// number is (v - 2^23) * 2^-23 -- an integer subtraction, a conversion and one exact scaling instead of a conversion and
+// three floating-point operations.  Same bits in double and in float (24 significant bits suffice), zero included (+0).
+template <typename real, bool COUNT>
+RTK_DEV real rnd_pm1(uint32_t& s, Counters<COUNT>& cnt) {
+    uint32_t old = s;
+    s = old * 747796405u + 2891336453u;
+    uint32_t w = ((old >> ((old >> 28u) + 4u)) ^ old) * 277803737u;
+    cnt.inc(C_RNG);
+    return real(int32_t(((w >> 22u) ^ w) >> 8) - 8388608) * real(1.0 / 8388608.0);
+}
 // vec3.h:107-115 -- always accepts; components drawn z, y, x.
 template <typename real, bool COUNT>
 RTK_DEV V3<real> random_unit_vector(uint32_t& s, Counters<COUNT>& cnt) {
-    real c = real(-1) + real(2) * rnd<real>(s, cnt);
-    real b = real(-1) + real(2) * rnd<real>(s, cnt);
-    real a = real(-1) + real(2) * rnd<real>(s, cnt);
+    real c = rnd_pm1<real>(s, cnt);
+    real b = rnd_pm1<real>(s, cnt);
+    real a = rnd_pm1<real>(s, cnt);
     V3<real> p = mk(a, b, c);
     return divide(p, rt_sqrt(length_squared(p)));
 }
@@ -1093,9 +1105,9 @@ RTK_DEV void begin_sample(Lane<real>& L, const CameraRec<real>& cam, int i, int 
     if (cam.defocus_angle > real(0)) {  // vec3.h:135-142
         real px, py;
         for (;;) {
-            py = real(-1) + real(2) * rnd<real>(L.rng, cnt);
-            px = real(-1) + real(2) * rnd<real>(L.rng, cnt);
-            if (px * px + py * py + real(0) * real(0) < real(1)) break;
+            py = rnd_pm1<real>(L.rng, cnt);
+            px = rnd_pm1<real>(L.rng, cnt);
+            if (px * px + py * py < real(1)) break;  // (the reference adds z * z = 0 * 0: x + 0 == x for x >= +0)
         }
         ro = ld3(cam.center) + scale(px, ld3(cam.disk_u)) + scale(py, ld3(cam.disk_v));
     }

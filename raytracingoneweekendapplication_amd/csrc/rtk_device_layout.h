@@ -44,6 +44,11 @@
 #define RTK_CH_BOX 1
 #endif
 
+// ... (RTK_CH_SCALED) with the ray parameter scaled per ray so that the current interval's end maps to 1: the two interval
+// clamps of the slab test become the free [0, 1] output clamp of v_max3 / v_min3 (rtk_trace.hip slab_test32_chs)
+#ifndef RTK_CH_SCALED
+#define RTK_CH_SCALED 1
+#endif
 // ... and (RTK_CH_BYTE_PC) that kernel's program counters and box links count bytes instead of 32-byte units
 #ifndef RTK_CH_BYTE_PC
 #define RTK_CH_BYTE_PC 1

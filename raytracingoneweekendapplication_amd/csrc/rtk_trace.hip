@@ -440,6 +440,7 @@ struct Lane {
     V3<float> oi32_lo;  // oi32 holds the UPPER bracket of o/d, this the lower one (see begin_culling32)
 #endif
     float tmin32, tmax32;
+    V3<float> inv32s, oi32s; // lean MIXED kernel (RTK_CH_SCALED): inv32 and oi32 times 1 / (end of the current interval), see rescale32
     float m2slack32;         // COMPACT kernels with centre / half-extent boxes: -2 x the ray's slack (slab_test32_che)
     real a, inv_a, tm;       // d.d (sphere.h:35, hoisted likewise) and 1/(d.d) for divide_by; ray time
     real tmin, best_t;       // current query interval: (tmin, closest so far)
@@ -532,6 +533,7 @@ RTK_DEV void begin_segment(Lane<real>& L, Counters<COUNT>& cnt, float extent = 0
     if constexpr (MIXED) {
         begin_culling32<CH>(L, L.ro, L.rd, extent);
         sync_interval32(L);
+        if constexpr (CH == 1 && RTK_CH_SCALED) rescale32(L, extent);
     } else {
         L.inv = mk(real(1) / L.rd.x, real(1) / L.rd.y, real(1) / L.rd.z);
         L.box_kind = regular_direction(L.inv) ? uint32_t(OP_BOX) : kIrregularBox;
@@ -559,21 +561,37 @@ struct NoTie {
     RTK_DEV bool inclusive_wins(uint32_t, uint32_t) const { return true; }
 };
 
+// RTK_CH_SCALED (lean MIXED kernel): the box test works in t' = t * s with s = 1 / (end of the current interval), so that
+// the interval is [~0, 1] and its two clamps are the output clamp of v_max3 / v_min3.  The end is tmax32 or, while there is
+// no hit yet, a bound no hit can exceed: origin and every box lie in [-extent, extent]^3, so a hit has
+// t <= 2 sqrt(3) extent / |d| <= 4 extent |1/d_x|.  s is rounded DOWN (v_rcp_f32 is good to an ulp; times 1 - 2^-22), so 1
+// maps to a t at or beyond the end; the lower clamp sits at t = 0 instead of tmin = 0.001 -- both on the permissive side.
+// The two extra roundings (inv * s, oi * s: 2^-24 each) are inside the margins the half-extents carry (rtk_api.cpp:
+// 3 x 2^-23 of the 4 x 2^-23 budgeted for the box's own share, 4.5 x 2^-23 of the 8 x 2^-23 for the origin's).
+template <typename real>
+RTK_DEV void rescale32(Lane<real>& L, float extent) {
+    const float bound = 4.0f * extent * __builtin_fabsf(L.inv32.x);
+    const float end = raw_min(L.tmax32, bound);
+    const float s = __builtin_amdgcn_rcpf(end) * 0.99999976f;
+    L.inv32s = V3<float>{L.inv32.x * s, L.inv32.y * s, L.inv32.z * s};
+    L.oi32s = V3<float>{L.oi32.x * s, L.oi32.y * s, L.oi32.z * s};
+}
 // A primitive test accepted t: it is the closest hit so far (hittable_list.h:27-31 / bvh.h:69 shrink the interval).
-template <bool MIXED, typename real>
-RTK_DEV void take_hit(Lane<real>& L, real t) {
+template <bool MIXED, bool SCALED = false, typename real>
+RTK_DEV void take_hit(Lane<real>& L, real t, float extent = 0.0f) {
     L.best_t = t;
     L.best_pc = L.pc;
     if constexpr (MIXED) L.tmax32 = above(t);
+    if constexpr (SCALED) rescale32(L, extent);
 }
 // The three primitive tests against the lane's current ray and interval, shared by every program layout: `units` is the
 // record's length in that layout; MIXED kernels keep the float copy of the interval in step.
-template <bool XF, bool MIXED, typename real, bool COUNT, typename Tie>
-RTK_DEV void hit_sphere(Lane<real>& L, V3<real> cc, real radius, uint32_t units, Counters<COUNT>& cnt, const Tie& tie) {
+template <bool XF, bool MIXED, bool SCALED = false, typename real, bool COUNT, typename Tie>
+RTK_DEV void hit_sphere(Lane<real>& L, V3<real> cc, real radius, uint32_t units, Counters<COUNT>& cnt, const Tie& tie, float extent = 0.0f) {
     cnt.inc(C_SPHERE);
     real r;
     if (sphere_root<Tie::enabled>(cc, radius, ray_o<XF>(L), ray_d<XF>(L), L.a, L.inv_a, L.tmin, L.best_t, r, [&] { return tie.sphere_wins(L.pc, L.best_pc); }))
-        take_hit<MIXED>(L, r);
+        take_hit<MIXED, SCALED>(L, r, extent);
     L.pc += units;
 }
 template <bool XF, bool MIXED, typename real, bool COUNT, typename Rec, typename Tie>
@@ -690,10 +708,27 @@ RTK_DEV void step_box32_che(Lane<real>& L, const MixedHead& rec, Counters<COUNT>
     const bool hit = slab_test32_che(rec, L.oi32, L.inv32, L.tmin32, L.tmax32, L.m2slack32);
     L.pc = hit ? L.pc + 2u : rec.aux;
 }
+// ... in the ray parameter scaled by rescale32: the interval is [0, 1], its clamps are output modifiers.  Strict compare: a
+// box has a positive extent along the ray (far' - near' = 2 h |inv'| > 0), so far' == near' after clamping means both were
+// clamped to the same end -- the box lies wholly before 0 or wholly beyond 1.
+RTK_DEV float max3_clamp01(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+RTK_DEV float min3_clamp01(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+RTK_DEV bool slab_test32_chs(const MixedHead& b, V3<float> oi, V3<float> inv) {
+    const float tcx = __builtin_fmaf(b.f(0), inv.x, -oi.x), tcy = __builtin_fmaf(b.f(1), inv.y, -oi.y), tcz = __builtin_fmaf(b.f(2), inv.z, -oi.z);
+    const float ax = __builtin_fabsf(inv.x), ay = __builtin_fabsf(inv.y), az = __builtin_fabsf(inv.z);
+    const float nx = __builtin_fmaf(-b.f(3), ax, tcx), fx = __builtin_fmaf(b.f(3), ax, tcx);
+    const float ny = __builtin_fmaf(-b.f(4), ay, tcy), fy = __builtin_fmaf(b.f(4), ay, tcy);
+    const float nz = __builtin_fmaf(-b.f(5), az, tcz), fz = __builtin_fmaf(b.f(5), az, tcz);
+    return min3_clamp01(fx, fy, fz) > max3_clamp01(nx, ny, nz);
+}
 template <typename real, bool COUNT>
 RTK_DEV void step_box32_ch(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cnt) {
     cnt.inc(C_BOX);
+#if RTK_CH_SCALED
+    const bool hit = slab_test32_chs(rec, L.oi32s, L.inv32s);
+#else
     const bool hit = slab_test32_ch(rec, L.oi32, L.inv32, L.tmin32, L.tmax32);
+#endif
     L.pc = hit ? L.pc + kChPcUnit : rec.aux;  // (pcs of this kernel count bytes, and so does the link)
 }
 // A box of those programs for a ray the float test must not judge (zero / out-of-range direction component, origin
@@ -717,9 +752,9 @@ RTK_DEV void step_box_mixed_exact(Lane<real>& L, const MixedHead& rec, Counters<
 }
 // sphere::hit on a MIXED record: centre in the head unit, radius in the next one.
 template <uint32_t PCU = 1, typename real, bool COUNT, typename Tie>
-RTK_DEV void step_sphere_mixed(Lane<real>& L, const MixedHead& head, const MixedHead* __restrict__ rec, Counters<COUNT>& cnt, const Tie& tie) {
+RTK_DEV void step_sphere_mixed(Lane<real>& L, const MixedHead& head, const MixedHead* __restrict__ rec, Counters<COUNT>& cnt, const Tie& tie, float extent) {
     const double radius = reinterpret_cast<const double*>(rec + 1)[0];
-    hit_sphere<false, true>(L, mk(real(head.d(0)), real(head.d(1)), real(head.d(2))), real(radius), 2u * PCU, cnt, tie);
+    hit_sphere<false, true, RTK_CH_BOX && RTK_CH_SCALED>(L, mk(real(head.d(0)), real(head.d(1)), real(head.d(2))), real(radius), 2u * PCU, cnt, tie, extent);
 }
 // ... and on a COMPACT record (3 units): the head (centre) is usually in registers already, the radius follows it.
 template <bool XF, typename real, bool COUNT, typename Tie>
@@ -728,14 +763,14 @@ RTK_DEV void step_sphere_compact(Lane<real>& L, const MixedHead& head, const Uni
 }
 // The remaining record kinds of a sphere-only program: a moving sphere, or a box for an irregular ray.
 template <uint32_t PCU = 1, typename real, bool COUNT, typename Tie>
-RTK_DEV void step_other_mixed(Lane<real>& L, const MixedHead* __restrict__ rec, Counters<COUNT>& cnt, const Tie& tie) {
+RTK_DEV void step_other_mixed(Lane<real>& L, const MixedHead* __restrict__ rec, Counters<COUNT>& cnt, const Tie& tie, float extent) {
     const uint32_t kind = rec->kind_payload & 15u;
     if (kind == OP_BOX) {
         step_box_mixed_exact<false, 1, PCU>(L, *rec, cnt);
     } else if (kind == OP_SPHERE_MOVING) {
         const double* cont = reinterpret_cast<const double*>(rec + 1);
         const V3<real> cc = mk(real(rec->d(0)), real(rec->d(1)), real(rec->d(2))) + scale(L.tm, mk(real(cont[2]), real(cont[3]), real(cont[4])));
-        hit_sphere<false, true>(L, cc, real(cont[0]), 3u * PCU, cnt, tie);
+        hit_sphere<false, true, RTK_CH_BOX && RTK_CH_SCALED>(L, cc, real(cont[0]), 3u * PCU, cnt, tie, extent);
     } else {
         L.pc += uint32_t(mixed_units(kind)) * PCU;  // unreachable for a validated sphere-only program
     }
@@ -1875,7 +1910,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
                     if (k == OP_SPHERE) {
                         if constexpr (SPLIT) cur = head_at(L.pc);
                         if constexpr (COMPACT) step_sphere_compact<XF>(L, cur, prog + L.pc, cnt, tie);
-                        else if constexpr (MIXED) step_sphere_mixed<kPcUnit>(L, cur, rec_at(L.pc), cnt, tie);
+                        else if constexpr (MIXED) step_sphere_mixed<kPcUnit>(L, cur, rec_at(L.pc), cnt, tie, extent);
                         else step_sphere<XF>(L, cur, cnt, tie);
                         fetch();
                         L.kind = k;
@@ -1938,7 +1973,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             do {
                 if (k == OP_SPHERE) {
                     if constexpr (COMPACT) step_sphere_compact<XF>(L, cur, prog + L.pc, cnt, tie);
-                    else if constexpr (MIXED) step_sphere_mixed<kPcUnit>(L, cur, rec_at(L.pc), cnt, tie);
+                    else if constexpr (MIXED) step_sphere_mixed<kPcUnit>(L, cur, rec_at(L.pc), cnt, tie, extent);
                     else step_sphere<XF>(L, cur, cnt, tie);
                     if constexpr (SPLIT) {
                         k = kind_of(L.pc);
@@ -2077,7 +2112,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             RTK_PROF_MARK(7, 1, popcount64(__ballot(alive)))
         } else {
             if (m_oth >> lane & 1ull) {
-                if constexpr (MIXED && !COMPACT) step_other_mixed<kPcUnit>(L, rec_at(L.pc), cnt, tie);
+                if constexpr (MIXED && !COMPACT) step_other_mixed<kPcUnit>(L, rec_at(L.pc), cnt, tie, extent);
                 else step_other<real, FEAT, COUNT>(L, prog + L.pc, sc, cnt, tie, extent);
                 L.kind = kind_of(L.pc);
             }

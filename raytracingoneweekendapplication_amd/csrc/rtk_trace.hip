@@ -509,10 +509,13 @@ RTK_DEV void begin_culling32(Lane<real>& L, V3<real> o, V3<real> d, float extent
         L.oi32 = V3<float>{L.oi32.x + e.x, L.oi32.y + e.y, L.oi32.z + e.z};
     }
 #endif
-    const float big = 3.0e38f;
+    // (RTK_CH_SCALED, lean MIXED kernel: the constants are multiplied once more by 1 / (end of the interval) <= 1, down to
+    // 2^-42 / extent -- direction components within 2^-40 .. 2^40 keep every product a normal float; anything else takes
+    // the exact path like a zero component does)
+    const float big = (CH == 1 && RTK_CH_SCALED) ? 1.0e12f : 3.0e38f, tiny = (CH == 1 && RTK_CH_SCALED) ? 1.0e-12f : 1.0e-30f;
     const bool ok = __builtin_fabsf(L.inv32.x) < big && __builtin_fabsf(L.inv32.y) < big && __builtin_fabsf(L.inv32.z) < big &&
                     __builtin_fabsf(d32.x) < big && __builtin_fabsf(d32.y) < big && __builtin_fabsf(d32.z) < big &&
-                    __builtin_fabsf(d32.x) > 1.0e-30f && __builtin_fabsf(d32.y) > 1.0e-30f && __builtin_fabsf(d32.z) > 1.0e-30f &&
+                    __builtin_fabsf(d32.x) > tiny && __builtin_fabsf(d32.y) > tiny && __builtin_fabsf(d32.z) > tiny &&
                     __builtin_fabsf(float(o.x)) <= extent && __builtin_fabsf(float(o.y)) <= extent && __builtin_fabsf(float(o.z)) <= extent;
     L.box_kind = ok ? uint32_t(OP_BOX) : kIrregularBox;
 }

@@ -73,10 +73,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 N_SIMDS = 256 * 4      # 256 CUs x 4 SIMD-32 (MI355X_MICROARCH.md, chip-level parameters)
 MAX_CLOCK_GHZ = 2.4    # max shader clock; the clock held during the profiled launch is GRBM_GUI_ACTIVE / 8 / kernel time
-PMC_ROUND = "r02"
+PMC_ROUND = "r03"
 WORKLOAD_NOTES = {"c4": "; the mesh is a procedural 1280-triangle stand-in for the reference's monkey.obj (a data asset that cannot travel to the GPU box, SURVEY 8(d))",
                   "c5": "; the earth texture is a procedural 1024x512 RGB8 stand-in for earthmap.jpg"}
 # what the render kernel and the program it executes are built from (rtk_multi.cpp / rtk.h only route calls: not part of the key)
+# Full-size framebuffer digests (f64 linear image, sha256[:16]) of the BASELINE configs at the committed seeds; the same
+# constants are asserted by tests/test_gpu_parity.py against oracle-probed renders.  Empty until measured on the device.
+PINNED_SHA256 = {}
 KERNEL_SOURCES = ("raytracingoneweekendapplication_amd/csrc/rtk_trace.hip", "raytracingoneweekendapplication_amd/csrc/rtk_api.cpp",
                   "raytracingoneweekendapplication_amd/csrc/rtk_optimize.cpp", "raytracingoneweekendapplication_amd/csrc/rtk_device_layout.h",
                   "raytracingoneweekendapplication_amd/csrc/rtk_trace.h")
@@ -110,14 +113,71 @@ def load_pmc(config, kernel, workload, n_gpus):
     return rec, os.path.relpath(path, ROOT)
 
 
-def valu_roofline(rec, kernel_ms):
+NOMINAL_ISSUE_CYCLES = {"f32": 2.0, "f64": 4.0, "trans_f32": 8.0, "trans_f64": 16.0, "mul_i32": 8.0}  # = tools/isa_costs.py NOMINAL_CYCLES
+
+
+def issue_cycles(measured=None):
+    """SIMD cycles a wave64 instruction of each class occupies the VALU issue for: measured on this box by
+    csrc/rtk_microbench.hip (8 waves per SIMD, 8 independent chains per lane: 1 / instructions per cycle per SIMD) or, when no
+    measurement is at hand, the nominal figures (MI355X_MICROARCH.md: v_fma_f32 2; f64 at half rate; transcendentals 4x)."""
+    if not measured:
+        return dict(NOMINAL_ISSUE_CYCLES), "nominal (MI355X_MICROARCH.md)"
+    inv = lambda key: 1.0 / measured[key] if measured.get(key, 0) > 0 else None
+    trans64 = [v for v in (inv("issue_v_rcp_f64"), inv("issue_v_rsq_f64"), inv("issue_v_sqrt_f64")) if v]
+    trans32 = [v for v in (inv("issue_v_rcp_f32"), inv("issue_v_sqrt_f32")) if v]
+    f64 = [v for v in (inv("issue_v_fma_f64"), inv("issue_v_mul_f64"), inv("issue_v_add_f64")) if v]
+    got = {"f32": inv("issue_v_fma_f32"), "f64": sum(f64) / len(f64) if f64 else None, "trans_f32": sum(trans32) / len(trans32) if trans32 else None,
+           "trans_f64": sum(trans64) / len(trans64) if trans64 else None, "mul_i32": inv("issue_v_mul_lo_u32")}
+    return {k: (round(v, 3) if v else NOMINAL_ISSUE_CYCLES[k]) for k, v in got.items()}, "measured (csrc/rtk_microbench.hip, this run)"
+
+
+def work_roofline(counters, isa, cycles, kernel_ms, spp_chunk=8):
+    """roofline.work_frac: the VALU issue time the FRAME'S WORK needs at full lanes / the issue time the launch had.
+    Numerator: exact work counters of the timed kernel's counting build x the instruction cost of each unit of work read from
+    the ISA (tools/isa_costs.py: a box step, a sphere test, the start of a segment / a sample, a miss, a surface interaction
+    priced at the CHEAPEST of the three materials, a partial-sum store per (pixel, chunk)), priced per class with `cycles`,
+    / 64 lanes.  Denominator: 1024 SIMDs x 2.4 GHz x kernel time.  Executing more instructions, or the same ones on emptier
+    waves, cannot raise it -- it is the fraction of the machine's VALU issue capacity that the necessary arithmetic of the
+    algorithm as implemented would occupy."""
+    cost = {k: sum(v[c] * cycles[c] for c in ("f32", "f64", "trans_f32", "trans_f64", "mul_i32")) for k, v in isa["costs"].items()}
+    hit = min(cost["lambertian"], cost["metal"], cost["dielectric"])
+    n = counters
+    units = {"box_step": (n["box_tests"], cost["box"]), "sphere_test": (n["sphere_tests"], cost["sphere"]), "segment_start": (n["segments"], cost["segment"]),
+             "sample_start": (n["samples"], cost["sample"]), "surface_hit_cheapest_material": (n["surface_hits"], hit),
+             "miss": (n["segments"] - n["surface_hits"], cost["miss"]), "partial_sum_store": (n["samples"] / float(spp_chunk), cost["partial"])}
+    lane_cycles = sum(w * c for w, c in units.values())          # SIMD cycles if every step ran on a wave of its own
+    needed = lane_cycles / 64.0                                  # ... on full waves
+    available = N_SIMDS * MAX_CLOCK_GHZ * 1e9 * kernel_ms * 1e-3
+    return {"work_frac": round(needed / available, 4),
+            "work_simd_cycles_per_sample": round(needed / n["samples"], 2),
+            "work_by_unit_share": {k: round(w * c / lane_cycles, 4) for k, (w, c) in units.items()},
+            "step_cost_simd_cycles": {k: round(v, 1) for k, v in cost.items()}}
+
+
+def load_isa_costs():
+    """profiles/<round>_isa_costs.json (tools/isa_costs.py --write), accepted only for the kernel sources it was derived from."""
+    path = os.path.join(ROOT, "profiles", f"{PMC_ROUND}_isa_costs.json")
+    if not os.path.exists(path):
+        return None, f"no profiles/{PMC_ROUND}_isa_costs.json"
+    rec = json.load(open(path))
+    if rec.get("source_hash") != kernel_source_hash():
+        return None, f"stale profiles/{PMC_ROUND}_isa_costs.json: derived from sources {rec.get('source_hash')!r}, this run has {kernel_source_hash()!r}"
+    return rec, os.path.relpath(path, ROOT)
+
+
+def valu_roofline(rec, kernel_ms, cycles=None):
     """VALU-issue roofline from PMC instruction counts (per launch) and the live kernel time.
     A CDNA4 SIMD is 32 lanes wide: a wave64 f32-class instruction occupies the pipe for 2 cycles, an f64 one for 4
-    (MI355X_MICROARCH.md: vector FP64 peak = half the FP32 peak; v_fma_f32 wave64 = 2 cycles on a SIMD-32)."""
+    (MI355X_MICROARCH.md: vector FP64 peak = half the FP32 peak; v_fma_f32 wave64 = 2 cycles on a SIMD-32); with `cycles`
+    (issue_cycles(): measured per class on this box) the f64 transcendentals (v_rcp / v_rsq / v_sqrt_f64) and the f32 ones are
+    priced at their own rates instead of the plain 4 / 2."""
     c = rec["counters"]
-    f64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_TRANS_F64"]
+    cycles = cycles or {"f32": 2.0, "f64": 4.0, "trans_f32": 2.0, "trans_f64": 4.0}
+    trans64, trans32 = c.get("SQ_INSTS_VALU_TRANS_F64", 0), c.get("SQ_INSTS_VALU_TRANS_F32", 0)
+    plain64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"]
+    f64 = plain64 + trans64
     valu = c["SQ_INSTS_VALU"]
-    pipe_cycles = 4.0 * f64 + 2.0 * (valu - f64)
+    pipe_cycles = cycles["f64"] * plain64 + cycles["trans_f64"] * trans64 + cycles["trans_f32"] * trans32 + cycles["f32"] * (valu - f64 - trans32)
     seconds = kernel_ms * 1e-3
     clock_ghz = MAX_CLOCK_GHZ
     if c.get("GRBM_GUI_ACTIVE") and rec.get("kernel_ms_profiled"):
@@ -129,7 +189,19 @@ def valu_roofline(rec, kernel_ms):
             "valu_lane_utilisation": round(lane_util, 4) if lane_util else None,
             "useful_lane_frac": round(achieved / peak * lane_util, 4) if lane_util else None,
             "valu_wave_insts_per_launch": int(valu), "f64_share": round(f64 / valu, 4), "clock_ghz_profiled": round(clock_ghz, 3),
-            "issue_cycles": {"f64": 4, "other": 2}}
+            "issue_cycles": cycles}
+
+
+def order_label(fast_scene, use_fast, verified):
+    """What `--order auto` relied on, for config.order: the fast order is PROVEN bit-identical for scenes without triangles
+    (rtk_optimize_info.exact == 2); with triangles it is identical in every measurement but not provable (== 1), and this run
+    then stands on its own check -- both orders rendered at full size, digests compared, a mismatch fails the run."""
+    if not use_fast:
+        return "reference (bvh.h)"
+    how = "proven bit-identical" if fast_scene.proven else ("empirically bit-identical" if fast_scene.exact else "statistical parity only")
+    if fast_scene.exact and not fast_scene.proven:
+        how += ", verified in this run: both orders rendered, digests equal" if verified else ", NOT verified in this run"
+    return f"fast (rtk_scene_upload_fast; {how})"
 
 
 def self_launch(args):
@@ -168,6 +240,7 @@ def parse_args():
                    help="visiting order: the reference's bvh_node order, rtk_scene_optimize's fast order, or fast where it is bit-identical (auto)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-f32", action="store_true")
+    p.add_argument("--no-microbench", action="store_true", help="skip the measured ceilings (HBM copy, LDS read, VALU issue rates); nominal issue costs are used")
     p.add_argument("--no-other-order", action="store_true", help="skip the untimed render in the other visiting order (profiling runs)")
     p.add_argument("--no-other-configs", action="store_true", help="skip the short measurements of the other BASELINE configs (N = 1, default config only)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
@@ -175,6 +248,14 @@ def parse_args():
                    help="2: frames alternate between two contexts and streams, so the end of one frame overlaps the start of the next; "
                         "1: one stream; 0 (default): 1 on one GPU (kernel durations in a rocprofv3 trace of this command then equal roofline.kernel_ms), 2 on several")
     p.add_argument("--sync-gather", action="store_true", help="N > 1: gather each frame before the next one is rendered (no overlap; dev A/B)")
+    p.add_argument("--multi", default="ranks", choices=["ranks", "abi"],
+                   help="N > 1: 'ranks' = one process per GPU, torch.distributed (RCCL) gather, the contract's launch; 'abi' = ONE process, "
+                        "the product's own rtk_init_multi / rtk_render_multi_enqueue / rtk_multi_wait over N devices (what camera::render with "
+                        "camera::devices does), two frames in flight.  Under the contract's launch rank 0 also runs the abi path in a child "
+                        "process after its own measurement (--no-abi-path skips it) and reports it under multi_paths")
+    p.add_argument("--multi-devices", default="", help="--multi abi: comma-separated HIP ordinals (default 0..N-1); an ordinal may repeat (one-GPU rehearsal)")
+    p.add_argument("--no-abi-path", action="store_true")
+    p.add_argument("--abi-timeout", type=float, default=240.0)
     p.add_argument("--rehearse-one-gpu", action="store_true",
                    help="dev only: run all ranks on device 0 with a gloo gather through host memory, to rehearse the N>1 control flow on a 1-GPU box")
     return p.parse_args()
@@ -221,8 +302,99 @@ def cpu_baseline(rt, scene_name, cam, earth, target_seconds):
             "sample": f"{scene_name} {W}x{H}x{spp}spp depth {depth}, CPU restatement (oracle/rt_oracle.cpp), {cores} threads, {t:.1f} s"}
 
 
+def run_abi(args):
+    """--multi abi: the product's own multi-GPU path behind the C ABI, one process, N devices, two frames in flight
+    (rtk_render_multi_enqueue / rtk_multi_wait, csrc/rtk_multi.cpp) -- what a sequence of camera::render calls with
+    camera::devices = {0..N-1} executes.  Prints one JSON line."""
+    import hashlib
+
+    import torch
+
+    import raytracingoneweekendapplication_amd as rt
+
+    devices = [int(x) for x in args.multi_devices.split(",")] if args.multi_devices else list(range(args.gpus))
+    n = len(devices)
+    scene_name = rt.CONFIG_SCENES[args.config]
+    tmp = tempfile.mkdtemp(prefix="rtk_bench_")
+    earth = rt.write_synthetic_earth(os.path.join(tmp, "earth_synth.ppm"))
+    scene = rt.Scene.build(scene_name, rt.SCENE_SEED, earth)
+    cam = scene.camera(args.width, args.height, args.spp, 0)
+    W, H, spp = cam.image_width, cam.image_height, cam.samples_per_pixel
+    fast_scene = scene.fast_order(cam.center)
+    use_fast = args.order == "fast" or (args.order == "auto" and fast_scene.exact)
+    multi = rt.MultiRenderer(devices)
+    multi.upload_fast(scene, cam.center) if use_fast else multi.upload(scene)
+    dev = torch.device("cuda", devices[0])
+    torch.cuda.set_device(dev)
+    images = [torch.empty((H, W, 3), dtype=torch.float64, device=dev) for _ in range(2)]
+    rgb8s = [torch.empty((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+
+    def sync_all():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    for k in range(max(args.warmup, 1)):  # every context learns its tile hand-out order from an untimed frame
+        multi.enqueue_device(cam, images[k % 2].data_ptr(), rgb8s[k % 2].data_ptr(), variant=args.variant)
+    multi.wait()
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        multi.enqueue_device(cam, images[k % 2].data_ptr(), rgb8s[k % 2].data_ptr(), variant=args.variant)
+    multi.wait()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    last = images[(args.steps - 1) % 2]
+    checksum = hashlib.sha256(last.cpu().numpy().tobytes()).hexdigest()[:16]
+    t0 = time.perf_counter()
+    for k in range(args.steps):  # the blocking form: what a single camera::render() call costs per frame
+        multi.render_device(cam, images[0].data_ptr(), rgb8s[0].data_ptr(), variant=args.variant)
+    sync_all()
+    blocking = time.perf_counter() - t0
+    samples = W * H * spp
+    line = {"metric": "Msamples/sec (pixels x spp) on RTIOW final scene 1920x1080", "value": round(samples * args.steps / elapsed / 1e6, 2), "unit": "Msamples/s",
+            "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{scene_name} {W}x{H}x{spp}spp depth {cam.max_depth} (BASELINE configs[{int(args.config[1]) - 1}])" + WORKLOAD_NOTES.get(args.config, ""),
+                       "parallelism": f"one process, rtk_render_multi_enqueue over devices {devices}: interleaved 8x8 tiles, one gather per frame "
+                                      f"({'ncclGather (RCCL)' if multi.uses_rccl else 'peer copies'}), two frames in flight",
+                       "order": order_label(fast_scene, use_fast, False), "reduced": bool(args.width or args.height or args.spp), "variant": args.variant},
+            "multi": "abi", "uses_rccl": multi.uses_rccl, "devices": devices,
+            "blocking_render_multi": {"value": round(samples * args.steps / blocking / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(blocking / args.steps * 1e3, 4),
+                                      "note": "rtk_render_multi_device per frame: enqueue + wait, no overlap between frames"},
+            "framebuffer_sha256": checksum}
+    print(json.dumps(line), flush=True)
+    multi.close()
+
+
+def abi_path_in_child(args, timeout_s):
+    """Rank 0 of the contract's launch: time the product's own multi-GPU path (--multi abi) over the same N devices in a child
+    process while the ranks idle.  Reported, never required: a failure or a timeout becomes an `error` string."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--multi", "abi", "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(max(args.warmup, 1)),
+           "--config", args.config, "--order", args.order]
+    for flag, val in (("--width", args.width), ("--height", args.height), ("--spp", args.spp), ("--variant", args.variant)):
+        if val:
+            cmd += [flag, str(val)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RTK_BENCH_CHILD",
+                                                              "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    try:
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        try:
+            out, err = proc.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            proc.communicate()
+            return {"error": f"timed out after {timeout_s:.0f} s"}
+        if proc.returncode != 0:
+            return {"error": f"exit code {proc.returncode}: {err.strip().splitlines()[-1] if err.strip() else ''}"[:300]}
+        return json.loads(out.strip().splitlines()[-1])
+    except Exception as exc:
+        return {"error": str(exc)[:300]}
+
+
 def main():
     args = parse_args()
+    if args.multi == "abi":
+        return run_abi(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
     if os.environ.get("RTK_BENCH_LAUNCH_ONLY"):  # tests of the launcher on boxes without a GPU: report the rank environment, touch nothing
@@ -265,7 +437,7 @@ def main():
     reduced = bool(args.width or args.height or args.spp)
     fast_scene = scene.fast_order(cam.center)
     use_fast = args.order == "fast" or (args.order == "auto" and fast_scene.exact)
-    order_name = "fast (rtk_scene_upload_fast)" if use_fast else "reference (bvh.h)"
+    order_name = order_label(fast_scene, use_fast, not args.no_other_order)
     renderer = rt.Renderer(local_rank)
     other_renderer = rt.Renderer(local_rank)
     for r_, fast_ in ((renderer, use_fast), (other_renderer, not use_fast)):
@@ -429,8 +601,40 @@ def main():
         rec, why = (None, "reduced workload: PMC profiles exist for the full-size configs only") if reduced or args.variant else load_pmc(args.config, kernel, workload, n)
         roofline = {"bound": "valu", "achieved": None, "peak": round(N_SIMDS * MAX_CLOCK_GHZ, 1), "unit": "G VALU pipe-cycles/s", "frac": None, "traffic": None,
                     "kernel": kernel, "kernel_ms": round(kernel_ms, 4)}
+        # measured ceilings of THIS box (csrc/rtk_microbench.hip): achievable HBM rate from a stream copy, the LDS
+        # read rate the byte model is served at, and the issue cost of each VALU class the roofline prices
+        measured, measured_why = None, None
+        if not args.no_microbench:
+            try:
+                measured = rt.microbench(local_rank)
+            except Exception as exc:  # a measurement tool: its absence degrades the line (nominal costs), never the run
+                measured_why = str(exc)[:200]
+        cycles, cycles_source = issue_cycles(measured)
+        roofline["ceilings"] = {"source": "csrc/rtk_microbench.hip, this run" if measured else f"unavailable: {measured_why}",
+                                "hbm_spec_GBps": HBM_PEAK_GBS,
+                                "hbm_copy_GBps": round(measured["hbm_copy_GBps"], 1) if measured else None,
+                                "hbm_read_GBps": round(measured["hbm_read_GBps"], 1) if measured else None,
+                                "lds_read_b128_GBps": round(measured["lds_read_b128_GBps"], 1) if measured else None,
+                                "lds_read_b128_random_records_GBps": round(measured["lds_read_b128_random_GBps"], 1) if measured else None,
+                                "lds_roundtrip_cycles": round(measured["lds_roundtrip_cycles"], 1) if measured else None,
+                                "shader_clock_GHz_under_valu_load": round(measured["shader_clock_GHz"], 3) if measured else None,
+                                "issue_cycles_per_wave_instruction": cycles, "issue_cycles_source": cycles_source,
+                                "issue_rates_measured": {k: round(v, 4) for k, v in measured.items() if k.startswith("issue_")} if measured else None}
+        if measured:
+            lds_rate = measured["lds_read_b128_random_GBps"]
+            hbm_model["model_vs_lds_ceiling"] = round(model_gbs / lds_rate, 4) if lds_rate > 0 else None
+            hbm_model["lds_ceiling_GBps"] = round(lds_rate, 1)
+            hbm_model["note"] += "; model_vs_lds_ceiling = model_GBps / the measured ds_read_b128 rate on random 32-byte records (what the box step reads)"
+        # the work-based fraction: exact work counters x ISA-derived cost per unit of work (lean MIXED kernel family)
+        isa, isa_why = load_isa_costs()
+        if isa is not None and mixed:
+            roofline.update(work_roofline(counters, isa, cycles, kernel_ms))
+            roofline["work_frac_source"] = {"isa_costs": isa_why, "issue_cycles": cycles_source, "counters": "counting build of the timed kernel, this run"}
+        else:
+            roofline["work_frac"] = None
+            roofline["work_frac_source"] = {"refused": isa_why if isa is None else "ISA cost table covers the lean MIXED kernel family only"}
         if rec is not None:
-            roofline.update(valu_roofline(rec, kernel_ms))
+            roofline.update(valu_roofline(rec, kernel_ms, cycles))
             roofline["traffic"] = rec.get("hbm_bytes_per_launch")
             roofline["hbm_traffic_GBps"] = round(rec["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9, 1) if rec.get("hbm_bytes_per_launch") else None
             roofline["hbm_frac_of_peak"] = round(roofline["hbm_traffic_GBps"] / HBM_PEAK_GBS, 5) if roofline["hbm_traffic_GBps"] else None
@@ -440,8 +644,11 @@ def main():
         else:
             roofline["pmc"] = {"source": None, "refused": why}
         roofline["hbm_model"] = hbm_model
-        roofline["note"] = ("frac = VALU pipe-cycles consumed (PMC wave-instruction counts x 2 cycles, f64 x 4) / (1024 SIMDs x 2.4 GHz x kernel time); "
-                            "useful_lane_frac = frac x VALU lane utilisation.  kernel_ms: HIP events on the launch stream, one launch alone on the device")
+        roofline["note"] = ("frac = VALU pipe-cycles consumed (PMC wave-instruction counts x the issue cycles of their class, ceilings.issue_cycles_per_wave_instruction) "
+                            "/ (1024 SIMDs x 2.4 GHz x kernel time): a utilisation of what was executed; useful_lane_frac = frac x VALU lane utilisation.  "
+                            "work_frac = (exact work counters x ISA-derived instruction cost per unit of work / 64 lanes) / the same denominator: what the frame's "
+                            "necessary arithmetic would occupy on full waves -- it cannot rise by executing more instructions.  kernel_ms: HIP events on the "
+                            "launch stream, one launch alone on the device")
 
     f32_mode = None
     if not args.no_f32:
@@ -456,32 +663,44 @@ def main():
     if rank == 0 and n == 1 and args.config == "c2" and not reduced and not args.variant and not args.no_other_configs:
         other_configs = {}
         for cfg in ("c3", "c4", "c5"):
-            try:
-                name_ = rt.CONFIG_SCENES[cfg]
-                scene_ = rt.Scene.build(name_, rt.SCENE_SEED, earth)
-                cam_ = scene_.camera(0, 0, 0, 0)
-                fast_ = scene_.fast_order(cam_.center)
-                r_ = rt.Renderer(local_rank)
-                r_.upload_fast(scene_, cam_.center) if fast_.exact else r_.upload(scene_)
-                W_, H_, spp_ = cam_.image_width, cam_.image_height, cam_.samples_per_pixel
-                img_ = torch.empty((H_, W_, 3), dtype=torch.float64, device=dev)
-                u8_ = torch.empty((H_, W_, 3), dtype=torch.uint8, device=dev)
-                frames = 2 if cfg == "c5" else 3
-                r_.render_device(cam_, img_.data_ptr(), u8_.data_ptr(), real_mode=rt.RTK_REAL_F64, stream=stream)  # untimed: learns the tile order
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(frames):
-                    r_.render_device(cam_, img_.data_ptr(), u8_.data_ptr(), real_mode=rt.RTK_REAL_F64, stream=stream)
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t0
-                other_configs[cfg] = {"workload": f"{name_} {W_}x{H_}x{spp_}spp depth {cam_.max_depth}" + WORKLOAD_NOTES.get(cfg, ""),
-                                      "value": round(W_ * H_ * spp_ * frames / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt / frames * 1e3, 3),
-                                      "steps": frames, "dtype": "f64", "order": "fast (rtk_scene_upload_fast)" if fast_.exact else "reference (bvh.h)",
-                                      "kernel": r_.kernel_name(rt.RTK_REAL_F64, 0),
-                                      "framebuffer_sha256": hashlib.sha256(img_.cpu().numpy().tobytes()).hexdigest()[:16]}
-                del r_, img_, u8_, scene_
-            except Exception as exc:  # reported, never required
-                other_configs[cfg] = {"value": None, "error": str(exc)}
+            # A failure here fails the run: an exception propagates, and a fast order that claims bit-identity is checked
+            # against the reference order at full size (one frame of the other order, digests compared) like the headline is.
+            name_ = rt.CONFIG_SCENES[cfg]
+            scene_ = rt.Scene.build(name_, rt.SCENE_SEED, earth)
+            cam_ = scene_.camera(0, 0, 0, 0)
+            fast_ = scene_.fast_order(cam_.center)
+            r_, r2_ = rt.Renderer(local_rank), rt.Renderer(local_rank)
+            for rr_, f_ in ((r_, fast_.exact), (r2_, not fast_.exact)):
+                rr_.upload_fast(scene_, cam_.center) if f_ else rr_.upload(scene_)
+            W_, H_, spp_ = cam_.image_width, cam_.image_height, cam_.samples_per_pixel
+            img_ = torch.empty((H_, W_, 3), dtype=torch.float64, device=dev)
+            u8_ = torch.empty((H_, W_, 3), dtype=torch.uint8, device=dev)
+            frames = 2 if cfg == "c5" else 3
+            r_.render_device(cam_, img_.data_ptr(), u8_.data_ptr(), real_mode=rt.RTK_REAL_F64, stream=stream)  # untimed: learns the tile order
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(frames):
+                r_.render_device(cam_, img_.data_ptr(), u8_.data_ptr(), real_mode=rt.RTK_REAL_F64, stream=stream)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            sha_ = hashlib.sha256(img_.cpu().numpy().tobytes()).hexdigest()[:16]
+            sha8_ = hashlib.sha256(u8_.cpu().numpy().tobytes()).hexdigest()[:16]
+            t0 = time.perf_counter()
+            r2_.render_device(cam_, img_.data_ptr(), u8_.data_ptr(), real_mode=rt.RTK_REAL_F64, stream=stream)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t0
+            sha2_ = hashlib.sha256(img_.cpu().numpy().tobytes()).hexdigest()[:16]
+            other_configs[cfg] = {"workload": f"{name_} {W_}x{H_}x{spp_}spp depth {cam_.max_depth}" + WORKLOAD_NOTES.get(cfg, ""),
+                                  "value": round(W_ * H_ * spp_ * frames / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt / frames * 1e3, 3),
+                                  "steps": frames, "dtype": "f64", "order": order_label(fast_, fast_.exact, True),
+                                  "kernel": r_.kernel_name(rt.RTK_REAL_F64, 0), "framebuffer_sha256": sha_, "rgb8_sha256": sha8_,
+                                  "other_order": {"order": "reference (bvh.h)" if fast_.exact else "fast (rtk_scene_upload_fast)", "framebuffer_sha256": sha2_,
+                                                  "value": round(W_ * H_ * spp_ / dt2 / 1e6, 2), "steps": 1, "identical_framebuffer": sha2_ == sha_}}
+            if fast_.exact and sha2_ != sha_:
+                raise SystemExit(f"{cfg}: the fast order claims bit-identity but the framebuffers differ: {sha_} vs {sha2_}")
+            if cfg in PINNED_SHA256 and not reduced and sha_ != PINNED_SHA256[cfg]:
+                raise SystemExit(f"{cfg}: framebuffer digest {sha_} differs from the pinned one {PINNED_SHA256[cfg]} (tests/test_gpu_parity.py pins the same values)")
+            del r_, r2_, img_, u8_, scene_
 
     cpu = None
     if rank == 0 and n == 1 and not args.no_cpu_baseline:
@@ -490,6 +709,20 @@ def main():
         except Exception as exc:  # the baseline is reported, never required
             cpu = {"value": None, "unit": "Msamples/s", "cores": host_cores(), "kind": "unavailable", "sample": f"failed: {exc}"}
 
+    # ---- N > 1: the product's own multi-GPU path (rtk_render_multi_enqueue behind the C ABI: one process, N devices) beside the
+    # torch.distributed ranks that were just timed -- in a child process of rank 0, while every rank idles at a CPU barrier
+    multi_paths = None
+    if n > 1 and not args.no_abi_path and not args.rehearse_one_gpu:
+        idle = dist.new_group(backend="gloo")
+        torch.cuda.synchronize()
+        dist.barrier(group=idle)
+        abi = abi_path_in_child(args, args.abi_timeout) if rank == 0 else None
+        dist.barrier(group=idle)
+        if rank == 0:
+            multi_paths = {"ranks": {"value": round(value, 2), "unit": "Msamples/s", "what": "one process per GPU, torch.distributed (RCCL) gather, two frames in flight: the value of this line"},
+                           "abi": ({k: abi.get(k) for k in ("value", "unit", "ms_per_step", "uses_rccl", "devices", "blocking_render_multi", "framebuffer_sha256", "error") if k in abi}
+                                   | {"what": "one process, rtk_render_multi_enqueue / rtk_multi_wait over the same devices (csrc/rtk_multi.cpp), two frames in flight"}),
+                           "identical_framebuffer": (abi.get("framebuffer_sha256") == checksum) if "framebuffer_sha256" in abi else None}
     if rank == 0:
         line = {
             "metric": "Msamples/sec (pixels x spp) on RTIOW final scene 1920x1080",
@@ -505,6 +738,7 @@ def main():
             "f32_mode": f32_mode,
             "other_order": other,
             "other_configs": other_configs,
+            "multi_paths": multi_paths,
             "speedup_vs_cpu_baseline": (round(value / cpu["value"], 1) if cpu and cpu.get("value") else None),
             "framebuffer_sha256": checksum,
         }

@@ -34,7 +34,11 @@
 extern "C" {
 #endif
 
-#define RTK_ABI_VERSION 1   /* additions since round 1 are new entry points only; no struct changed */
+/* 2: rtk_optimize_opts grew by free_media_order (40 -> 48 bytes; the entry points that take it copy it by value, so a
+ * caller built against version 1 must be rebuilt), rtk_optimize_info.exact became three-valued, new entry points
+ * (rtk_multi_*, rtk_render_multi_enqueue / rtk_multi_wait, rtk_debug_*).  Every rtk_scene_desc carries the version it was
+ * built against and is refused when it differs (rtk_scene_upload, rtk_scene_optimize). */
+#define RTK_ABI_VERSION 2
 
 typedef enum rtk_status {
     RTK_OK = 0,
@@ -266,7 +270,7 @@ int rtk_scene_validate(const rtk_scene_desc* scene, int32_t* n_program_ops);
  * median split, bvh.h:64-72 left then right) stays the default everywhere else.
  * The closest hit of every ray is preserved and exact ties go to the primitive
  * the reference would have kept (rtk_node.c ranks), so the image is bit-identical
- * (info->exact = 1).  A constant_medium draws a random number inside hit()
+ * (info->exact = 2: proven; 1 for scenes with triangles: measured, not provable).  A constant_medium draws a random number inside hit()
  * (constant_medium.h:40), so it must be called with the interval the reference
  * calls it with: media (and instances holding one) keep their position in the
  * reference's visiting order and only the runs of objects between them are
@@ -287,16 +291,21 @@ typedef struct rtk_optimize_opts {
     int32_t free_media_order; /* 0 (default): a constant_medium keeps its position in the reference's visiting order -- it is
                                * called after exactly the objects that precede it there -- so it meets the same interval
                                * and draws the same random numbers as in the reference: the image stays bit-identical
-                               * (info->exact = 1).  != 0: media are re-grouped like any other object; the order of the
+                               * (info->exact >= 1).  != 0: media are re-grouped like any other object; the order of the
                                * draws inside constant_medium::hit changes and parity becomes statistical */
     int32_t _pad;
 } rtk_optimize_opts;
 
 typedef struct rtk_optimize_info {
-    int32_t exact;              /* 1: images are bit-identical to the reference order */
+    int32_t exact;              /* 2: images are PROVEN bit-identical to the reference order (closest hits preserved, ties by
+                                 * reference rank, media at their reference positions).  1: EMPIRICALLY identical -- the scene
+                                 * has triangles (see has_triangles): identical in every measurement, not provable; verify
+                                 * (render both orders) or opt in before relying on it.  0: statistical parity only
+                                 * (opts->free_media_order) */
     int32_t has_media;          /* a constant_medium draws inside hit(): exact only while opts->free_media_order == 0 */
     int32_t has_triangles;      /* triangle::hit's float determinant (triangle.h:72,77): identical except where the
-                                 * reference's own boxes cull a hit that triangle::hit accepts (order-dependent) */
+                                 * reference's own boxes cull a hit that triangle::hit accepts (order-dependent);
+                                 * caps `exact` at 1 */
     int32_t n_bvh_nodes_in, n_bvh_nodes_out;
     int32_t n_ordered_items;    /* media, and instances holding one, that kept their position in the reference's order */
     double expected_cost;       /* SAH estimate, in slab tests, of one closest-hit query */
@@ -394,6 +403,18 @@ int rtk_multi_scene_upload_fast(rtk_multi* multi, const rtk_scene_desc* scene, c
  * returns (blocking).  opts->rank / n_ranks / stream are ignored (the call owns the split). */
 int rtk_render_multi_device(rtk_multi* multi, const rtk_camera* cam, const rtk_render_opts* opts,
                             void* d_linear, uint8_t* d_rgb8);
+/* The asynchronous form: returns when the frame's work has been enqueued -- the renders on each device's stream, the
+ * gather and the un-permute on per-device transfer streams -- with up to two frames in flight: frame k + 1 renders into a
+ * second set of tile buffers while frame k is gathered and un-permuted (frame k + 2 waits on the device for frame k's
+ * release; the host never blocks here).  d_linear / d_rgb8 (on the first device, either may be NULL) must stay valid
+ * until rtk_multi_wait returns; frames that name the same buffers overwrite them in order.  rtk_multi_wait blocks until
+ * every enqueued frame is complete (progress callbacks run from it).  rtk_render_multi_device = enqueue + wait. */
+int rtk_render_multi_enqueue(rtk_multi* multi, const rtk_camera* cam, const rtk_render_opts* opts,
+                             void* d_linear, uint8_t* d_rgb8);
+int rtk_multi_wait(rtk_multi* multi);
+/* Host-only, no device needed: the buffer-set rule rtk_render_multi_enqueue follows for frame number `frame`
+ * (0, 1, 2, ...): out[0] = buffer set, out[1] = 1 when the renders first wait for that set's release by frame - 2. */
+int rtk_multi_frame_plan(int64_t frame, int32_t out[2]);
 /* The same into host buffers (h_linear: H*W*3 doubles, F32 results widened), as rtk_render_host. */
 int rtk_render_multi(rtk_multi* multi, const rtk_camera* cam, const rtk_render_opts* opts,
                      double* h_linear, uint8_t* h_rgb8);
@@ -402,11 +423,12 @@ int rtk_render_multi(rtk_multi* multi, const rtk_camera* cam, const rtk_render_o
  * The reference prints "Scanlines remaining" from an atomic the row workers bump
  * (Camera.txt:63,91,102-106).  Here the render kernel's work-item counter plays
  * that role: while a blocking render (rtk_render_host, rtk_render_multi*) runs,
- * the calling thread polls it off the device path -- a host-mapped word the kernel's
- * existing hand-out atomic is mirrored into; the kernel does no extra work -- and
- * calls `fn(done, total, user)` with done/total in work items (8x8 tile x sample
- * chunk), at most every `interval_ms` (<= 0: 100 ms).  fn == NULL switches it off.
- * Never called from another thread. */
+ * the calling thread samples it off the kernel's path -- a 4-byte device-to-host
+ * hipMemcpyAsync of the counter into a pinned word, on a stream of its own (the
+ * copy engine; the persistent kernel does no extra work, and a sample that has not
+ * landed by the next tick is skipped) -- and calls `fn(done, total, user)` with
+ * done/total in work items (8x8 tile x sample chunk), at most every `interval_ms`
+ * (<= 0: 100 ms).  fn == NULL switches it off.  Never called from another thread. */
 typedef void (*rtk_progress_fn)(int64_t done, int64_t total, void* user);
 int rtk_set_progress_callback(rtk_ctx* ctx, rtk_progress_fn fn, void* user, int interval_ms);
 
@@ -420,6 +442,22 @@ int rtk_set_progress_callback(rtk_ctx* ctx, rtk_progress_fn fn, void* user, int 
  * Blocking; not a rendering path. */
 int rtk_debug_closest_hit(rtk_ctx* ctx, int real_mode, int n, const double* h_rays, const uint32_t* h_keys,
                           double* h_out, uint64_t* h_draws);
+
+/* The same for the shading side, on the device functions the render kernel itself executes (blocking; not rendering paths):
+ *   rtk_debug_scatter   material::scatter + emitted (material.h:22-172) of materials[h_materials[k]] for a caller-supplied
+ *                       hit record:  h_rays[n][7] = origin(3), direction(3), time;  h_records[n][11] = t, p(3), normal(3),
+ *                       front_face, u, v, (unused);  h_keys[n][3] = seed, pixel, sample of the RNG stream scatter() draws from;
+ *                       h_out[n][14] = scattered (0/1), scattered ray origin(3) direction(3), attenuation(3), time, emitted(3);
+ *                       h_draws[n] = random_double() calls consumed
+ *   rtk_debug_texture   texture::value(u, v, p) (texture.h:20-120, perlin.h:14-50) of textures[h_textures[k]]:
+ *                       h_uvp[n][5] = u, v, p(3);  h_out[n][3] = colour;  h_work[n][2] = perlin::noise calls, texel fetches
+ *   rtk_debug_get_ray   camera::get_ray (Camera.txt:177-200) of `cam` for h_pixel_sample[n][3] = i, j, sample:
+ *                       h_out[n][7] = origin(3), direction(3), time;  h_draws[n] = random_double() calls consumed */
+int rtk_debug_scatter(rtk_ctx* ctx, int real_mode, int n, const int32_t* h_materials, const double* h_rays, const double* h_records,
+                      const uint32_t* h_keys, double* h_out, uint64_t* h_draws);
+int rtk_debug_texture(rtk_ctx* ctx, int real_mode, int n, const int32_t* h_textures, const double* h_uvp, double* h_out, uint64_t* h_work);
+int rtk_debug_get_ray(rtk_ctx* ctx, int real_mode, const rtk_camera* cam, uint32_t seed, int n, const int32_t* h_pixel_sample,
+                      double* h_out, uint64_t* h_draws);
 
 /* Introspection of the uploaded scene's traversal program (for tests and
  * for the byte model): number of program slots (fused records) and device bytes per mode. */

@@ -18,10 +18,16 @@ from typing import Optional
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_PKG_DIR)
-HIP_LIB_PATH = os.environ.get("RTK_HIP_LIB") or os.path.join(_PKG_DIR, "librtk_hip.so")  # the override is for tools/ (diagnostic builds)
+DEFAULT_HIP_LIB_PATH = os.path.join(_PKG_DIR, "librtk_hip.so")
+# RTK_HIP_LIB substitutes a diagnostic build (tools/: A/B libraries, the -DRTK_PROFILE build) and is honoured only together
+# with RTK_DEV_TOOLS=1: a stray RTK_HIP_LIB in the environment of a test or bench run is an error, never a silent swap.
+if os.environ.get("RTK_HIP_LIB") and os.environ.get("RTK_DEV_TOOLS") != "1":
+    raise ImportError("RTK_HIP_LIB is set without RTK_DEV_TOOLS=1: refusing to load a substitute kernel library "
+                      f"({os.environ['RTK_HIP_LIB']}) in place of {DEFAULT_HIP_LIB_PATH}")
+HIP_LIB_PATH = os.environ.get("RTK_HIP_LIB") or DEFAULT_HIP_LIB_PATH
 HOST_LIB_PATH = os.path.join(_PKG_DIR, "librtk_host.so")
 
-RTK_ABI_VERSION = 1
+RTK_ABI_VERSION = 2
 RTK_REAL_F64 = 0
 RTK_REAL_F32 = 1
 TILE_PIXELS = 64
@@ -88,7 +94,10 @@ def _optimize_opts(eye, max_leaf, prim_cost_scale, free_media_order) -> Optimize
 
 
 def _optimize_info(info: OptimizeInfo) -> dict:
-    return {"exact": bool(info.exact), "has_media": bool(info.has_media), "has_triangles": bool(info.has_triangles),
+    # exact: rtk_optimize_info.exact != 0 (bit-identical to the reference order); proven: == 2 (no triangles -- with them it is
+    # identical in every measurement but not provable, include/rtk.h)
+    return {"exact": bool(info.exact), "proven": info.exact == 2, "exactness": int(info.exact),
+            "has_media": bool(info.has_media), "has_triangles": bool(info.has_triangles),
             "n_bvh_nodes_in": info.n_bvh_nodes_in, "n_bvh_nodes_out": info.n_bvh_nodes_out, "n_ordered_items": info.n_ordered_items,
             "expected_cost": info.expected_cost, "box_margin": info.box_margin}
 
@@ -185,6 +194,9 @@ def hip_lib() -> C.CDLL:
         lib.rtk_render_host.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rtk_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.rtk_debug_closest_hit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.rtk_debug_scatter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.rtk_debug_texture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.rtk_debug_get_ray.argtypes = [C.c_void_p, C.c_int, C.POINTER(Camera), C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rtk_scene_optimize.argtypes = [C.c_void_p, C.POINTER(OptimizeOpts), C.POINTER(C.c_void_p), C.POINTER(OptimizeInfo)]
         lib.rtk_scene_upload_fast.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OptimizeOpts), C.POINTER(OptimizeInfo)]
         lib.rtk_scene_optimized_free.restype = None
@@ -202,11 +214,33 @@ def hip_lib() -> C.CDLL:
         lib.rtk_multi_scene_upload_fast.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OptimizeOpts), C.POINTER(OptimizeInfo)]
         lib.rtk_render_multi_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p, C.c_void_p]
         lib.rtk_render_multi.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p, C.c_void_p]
+        lib.rtk_render_multi_enqueue.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p, C.c_void_p]
+        lib.rtk_multi_wait.argtypes = [C.c_void_p]
+        lib.rtk_multi_frame_plan.argtypes = [C.c_int64, C.POINTER(C.c_int32)]
         lib.rtk_set_progress_callback.argtypes = [C.c_void_p, PROGRESS_FN, C.c_void_p, C.c_int]
         if lib.rtk_abi_version() != RTK_ABI_VERSION:
             raise RuntimeError("librtk_hip.so ABI version mismatch")
         _hip_lib = lib
     return _hip_lib
+
+
+MICROBENCH_LIB_PATH = os.path.join(_PKG_DIR, "librtk_microbench.so")
+
+
+def microbench(device: int = 0) -> dict:
+    """Measured ceilings of the box (csrc/rtk_microbench.hip): HBM stream copy, LDS read rates, VALU issue rates per class.
+    A measurement tool for bench.py's roofline object; raises when the library or a device is missing."""
+    if not os.path.exists(MICROBENCH_LIB_PATH):
+        raise RuntimeError(f"{MICROBENCH_LIB_PATH} not built (run __graft_entry__.build())")
+    lib = C.CDLL(MICROBENCH_LIB_PATH)
+    lib.rtk_microbench_names.restype = C.c_char_p
+    lib.rtk_microbench_last_error.restype = C.c_char_p
+    names = lib.rtk_microbench_names().decode().split(",")
+    out = (C.c_double * len(names))()
+    rc = lib.rtk_microbench_run(device, out, len(names))
+    if rc != 0:
+        raise RuntimeError(f"rtk_microbench_run failed ({rc}): {lib.rtk_microbench_last_error().decode()}")
+    return dict(zip(names, [float(v) for v in out]))
 
 
 def tiles_per_rank(width: int, height: int, n_ranks: int) -> int:
@@ -269,7 +303,8 @@ class FastOrderScene:
     """rtk_scene_optimize output: a description that borrows the tables of `base` (kept alive here).
 
     ``exact`` says whether rendering it gives bit-identical images to the reference order (always, unless media were
-    re-grouped too: ``free_media_order``).
+    re-grouped too: ``free_media_order``); ``proven`` whether that is a proof (scenes without triangles) or a
+    measurement (``rtk_optimize_info.exact`` 2 vs 1).
     """
 
     def __init__(self, base: Scene, eye: Optional[Vec3] = None, max_leaf: int = 0, prim_cost_scale: float = 0.0, free_media_order: bool = False):
@@ -282,6 +317,7 @@ class FastOrderScene:
             raise RtkError(rc, "rtk_scene_optimize failed")
         self._h = out.value
         self.exact = bool(info.exact)
+        self.proven = info.exact == 2
         self.info = _optimize_info(info)
 
     @property
@@ -421,6 +457,41 @@ class Renderer:
         self._check(self._lib.rtk_debug_closest_hit(self._ctx, real_mode, n, rays.ctypes.data, keys.ctypes.data, out.ctypes.data, draws.ctypes.data))
         return out, draws
 
+    def debug_scatter(self, materials, rays, records, keys, real_mode: int = RTK_REAL_F64):
+        """rtk_debug_scatter: (out [n][14] = scattered, scattered ray o(3) d(3), attenuation(3), time, emitted(3); draws [n])."""
+        import numpy as np
+
+        materials = np.ascontiguousarray(materials, np.int32)
+        rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 7)
+        records = np.ascontiguousarray(records, np.float64).reshape(-1, 11)
+        keys = np.ascontiguousarray(keys, np.uint32).reshape(-1, 3)
+        n = materials.shape[0]
+        out, draws = np.zeros((n, 14), np.float64), np.zeros(n, np.uint64)
+        self._check(self._lib.rtk_debug_scatter(self._ctx, real_mode, n, materials.ctypes.data, rays.ctypes.data, records.ctypes.data, keys.ctypes.data,
+                                                out.ctypes.data, draws.ctypes.data))
+        return out, draws
+
+    def debug_texture(self, textures, uvp, real_mode: int = RTK_REAL_F64):
+        """rtk_debug_texture: (colour [n][3], work [n][2] = perlin::noise calls, texel fetches)."""
+        import numpy as np
+
+        textures = np.ascontiguousarray(textures, np.int32)
+        uvp = np.ascontiguousarray(uvp, np.float64).reshape(-1, 5)
+        n = textures.shape[0]
+        out, work = np.zeros((n, 3), np.float64), np.zeros((n, 2), np.uint64)
+        self._check(self._lib.rtk_debug_texture(self._ctx, real_mode, n, textures.ctypes.data, uvp.ctypes.data, out.ctypes.data, work.ctypes.data))
+        return out, work
+
+    def debug_get_ray(self, cam: Camera, seed: int, pixel_sample, real_mode: int = RTK_REAL_F64):
+        """rtk_debug_get_ray: (ray [n][7] = origin, direction, time; draws [n]) for pixel_sample [n][3] = i, j, sample."""
+        import numpy as np
+
+        ijs = np.ascontiguousarray(pixel_sample, np.int32).reshape(-1, 3)
+        n = ijs.shape[0]
+        out, draws = np.zeros((n, 7), np.float64), np.zeros(n, np.uint64)
+        self._check(self._lib.rtk_debug_get_ray(self._ctx, real_mode, C.byref(cam), seed, n, ijs.ctypes.data, out.ctypes.data, draws.ctypes.data))
+        return out, draws
+
     def set_progress(self, fn=None, interval_ms: int = 100) -> None:
         """rtk_set_progress_callback: ``fn(done, total)`` is called from the thread that runs a blocking render
         (render_host), at most every ``interval_ms``; None switches it off."""
@@ -490,6 +561,16 @@ class MultiRenderer:
         """rtk_render_multi_device: blocking; the image is resident on devices[0] on return."""
         opts = RenderOpts(seed, real_mode, 0, 1, 0, variant, None)
         self._check(self._lib.rtk_render_multi_device(self._m, C.byref(cam), C.byref(opts), d_linear or None, d_rgb8 or None))
+
+    def enqueue_device(self, cam: Camera, d_linear: int, d_rgb8: int = 0, *, seed: int = RENDER_SEED, real_mode: int = RTK_REAL_F64, variant: int = 0) -> None:
+        """rtk_render_multi_enqueue: returns once the frame is enqueued (two frames in flight: this frame's gather and
+        un-permute overlap the next frame's renders); the buffers must stay valid until wait()."""
+        opts = RenderOpts(seed, real_mode, 0, 1, 0, variant, None)
+        self._check(self._lib.rtk_render_multi_enqueue(self._m, C.byref(cam), C.byref(opts), d_linear or None, d_rgb8 or None))
+
+    def wait(self) -> None:
+        """rtk_multi_wait: every enqueued frame is complete on devices[0]."""
+        self._check(self._lib.rtk_multi_wait(self._m))
 
     def close(self) -> None:
         if getattr(self, "_m", None):

@@ -913,6 +913,7 @@ struct rtk_ctx {
     bool has_scene = false;
     uint32_t features = 0;
     int32_t n_ops = 0;
+    int32_t n_materials = 0, n_textures = 0;  // of the uploaded description (index checks of the known-answer entry points)
     DeviceScene<double> scene64;
     DeviceScene<float> scene32;
     // Words the persistent waves pull tile indices from; one per launch in a
@@ -1030,6 +1031,34 @@ int wait_with_progress(rtk_ctx* const* ctxs, const hipStream_t* streams, int n) 
 }
 
 }  // namespace rtk
+
+namespace {
+// Device buffers of a known-answer call: released on every path out.
+struct KatBuffers {
+    std::vector<void*> ptrs;
+    hipError_t err = hipSuccess;
+    template <typename T>
+    T* in(const T* host, size_t count) {
+        T* d = out<T>(count);
+        if (d && err == hipSuccess) err = hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice);
+        return d;
+    }
+    template <typename T>
+    T* out(size_t count) {
+        void* d = nullptr;
+        if (err == hipSuccess) err = hipMalloc(&d, count * sizeof(T) > 0 ? count * sizeof(T) : 16);
+        if (d) ptrs.push_back(d);
+        return static_cast<T*>(d);
+    }
+    template <typename T>
+    void back(T* host, const T* dev, size_t count) {
+        if (err == hipSuccess) err = hipMemcpy(host, dev, count * sizeof(T), hipMemcpyDeviceToHost);
+    }
+    ~KatBuffers() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+};
+}  // namespace
 
 extern "C" {
 
@@ -1178,6 +1207,8 @@ static int upload_scene(rtk_ctx* ctx, const rtk_scene_desc* scene, UploadOrder o
     if ((rc = build_device_scene<float>(*scene, prog, ctx->scene32, fast_order)) != RTK_OK) return rc;
     ctx->features = prog.features | hierarchy_flags;
     ctx->n_ops = int32_t(prog.ops.size());
+    ctx->n_materials = scene->n_materials;
+    ctx->n_textures = scene->n_textures;
     ctx->has_scene = true;
     return RTK_OK;
 }
@@ -1405,6 +1436,75 @@ int rtk_debug_closest_hit(rtk_ctx* ctx, int real_mode, int n, const double* h_ra
     if (e == hipSuccess) e = hipMemcpy(h_draws, d_draws, size_t(n) * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     cleanup();
     if (e != hipSuccess) return fail(RTK_ERR_HIP, "rtk_debug_closest_hit: %s", hipGetErrorString(e));
+    return RTK_OK;
+}
+
+int rtk_debug_scatter(rtk_ctx* ctx, int real_mode, int n, const int32_t* h_materials, const double* h_rays, const double* h_records, const uint32_t* h_keys,
+                      double* h_out, uint64_t* h_draws) {
+    if (!ctx || n < 0 || !h_materials || !h_rays || !h_records || !h_keys || !h_out || !h_draws) return fail(RTK_ERR_INVALID, "rtk_debug_scatter: bad argument");
+    if (!ctx->has_scene) return fail(RTK_ERR_NO_SCENE, "rtk_debug_scatter: no scene uploaded");
+    if (real_mode != RTK_REAL_F64 && real_mode != RTK_REAL_F32) return fail(RTK_ERR_INVALID, "rtk_debug_scatter: unknown real_mode %d", real_mode);
+    for (int k = 0; k < n; k++)
+        if (h_materials[k] < 0 || h_materials[k] >= ctx->n_materials) return fail(RTK_ERR_INVALID, "rtk_debug_scatter: material %d of case %d out of range", h_materials[k], k);
+    if (n == 0) return RTK_OK;
+    RTK_HIP(hipSetDevice(ctx->device));
+    KatBuffers b;
+    const int32_t* d_mat = b.in(h_materials, size_t(n));
+    const double* d_ray = b.in(h_rays, size_t(n) * 7);
+    const double* d_rec = b.in(h_records, size_t(n) * 11);
+    const uint32_t* d_keys = b.in(h_keys, size_t(n) * 3);
+    double* d_out = b.out<double>(size_t(n) * 14);
+    auto* d_draws = b.out<unsigned long long>(size_t(n));
+    if (b.err == hipSuccess)
+        b.err = real_mode == RTK_REAL_F64 ? launch_debug_scatter<double>(ctx->scene64.view, n, d_mat, d_ray, d_rec, d_keys, d_out, d_draws, nullptr)
+                                          : launch_debug_scatter<float>(ctx->scene32.view, n, d_mat, d_ray, d_rec, d_keys, d_out, d_draws, nullptr);
+    if (b.err == hipSuccess) b.err = hipDeviceSynchronize();
+    b.back(h_out, d_out, size_t(n) * 14);
+    b.back(reinterpret_cast<unsigned long long*>(h_draws), d_draws, size_t(n));
+    if (b.err != hipSuccess) return fail(RTK_ERR_HIP, "rtk_debug_scatter: %s", hipGetErrorString(b.err));
+    return RTK_OK;
+}
+
+int rtk_debug_texture(rtk_ctx* ctx, int real_mode, int n, const int32_t* h_textures, const double* h_uvp, double* h_out, uint64_t* h_work) {
+    if (!ctx || n < 0 || !h_textures || !h_uvp || !h_out || !h_work) return fail(RTK_ERR_INVALID, "rtk_debug_texture: bad argument");
+    if (!ctx->has_scene) return fail(RTK_ERR_NO_SCENE, "rtk_debug_texture: no scene uploaded");
+    if (real_mode != RTK_REAL_F64 && real_mode != RTK_REAL_F32) return fail(RTK_ERR_INVALID, "rtk_debug_texture: unknown real_mode %d", real_mode);
+    for (int k = 0; k < n; k++)
+        if (h_textures[k] < 0 || h_textures[k] >= ctx->n_textures) return fail(RTK_ERR_INVALID, "rtk_debug_texture: texture %d of case %d out of range", h_textures[k], k);
+    if (n == 0) return RTK_OK;
+    RTK_HIP(hipSetDevice(ctx->device));
+    KatBuffers b;
+    const int32_t* d_tex = b.in(h_textures, size_t(n));
+    const double* d_uvp = b.in(h_uvp, size_t(n) * 5);
+    double* d_out = b.out<double>(size_t(n) * 3);
+    auto* d_work = b.out<unsigned long long>(size_t(n) * 2);
+    if (b.err == hipSuccess)
+        b.err = real_mode == RTK_REAL_F64 ? launch_debug_texture<double>(ctx->scene64.view, n, d_tex, d_uvp, d_out, d_work, nullptr)
+                                          : launch_debug_texture<float>(ctx->scene32.view, n, d_tex, d_uvp, d_out, d_work, nullptr);
+    if (b.err == hipSuccess) b.err = hipDeviceSynchronize();
+    b.back(h_out, d_out, size_t(n) * 3);
+    b.back(reinterpret_cast<unsigned long long*>(h_work), d_work, size_t(n) * 2);
+    if (b.err != hipSuccess) return fail(RTK_ERR_HIP, "rtk_debug_texture: %s", hipGetErrorString(b.err));
+    return RTK_OK;
+}
+
+int rtk_debug_get_ray(rtk_ctx* ctx, int real_mode, const rtk_camera* cam, uint32_t seed, int n, const int32_t* h_pixel_sample, double* h_out, uint64_t* h_draws) {
+    if (!ctx || !cam || n < 0 || !h_pixel_sample || !h_out || !h_draws) return fail(RTK_ERR_INVALID, "rtk_debug_get_ray: bad argument");
+    if (real_mode != RTK_REAL_F64 && real_mode != RTK_REAL_F32) return fail(RTK_ERR_INVALID, "rtk_debug_get_ray: unknown real_mode %d", real_mode);
+    if (cam->image_width <= 0 || cam->image_height <= 0) return fail(RTK_ERR_INVALID, "rtk_debug_get_ray: bad camera dimensions");
+    if (n == 0) return RTK_OK;
+    RTK_HIP(hipSetDevice(ctx->device));
+    KatBuffers b;
+    const int32_t* d_ijs = b.in(h_pixel_sample, size_t(n) * 3);
+    double* d_out = b.out<double>(size_t(n) * 7);
+    auto* d_draws = b.out<unsigned long long>(size_t(n));
+    if (b.err == hipSuccess)
+        b.err = real_mode == RTK_REAL_F64 ? launch_debug_get_ray<double>(to_device_camera<double>(*cam), seed, n, d_ijs, d_out, d_draws, nullptr)
+                                          : launch_debug_get_ray<float>(to_device_camera<float>(*cam), seed, n, d_ijs, d_out, d_draws, nullptr);
+    if (b.err == hipSuccess) b.err = hipDeviceSynchronize();
+    b.back(h_out, d_out, size_t(n) * 7);
+    b.back(reinterpret_cast<unsigned long long*>(h_draws), d_draws, size_t(n));
+    if (b.err != hipSuccess) return fail(RTK_ERR_HIP, "rtk_debug_get_ray: %s", hipGetErrorString(b.err));
     return RTK_OK;
 }
 

@@ -11,7 +11,10 @@
 //     ncclCommInitAll, the n calls grouped), or -- when a device is listed twice, or librccl cannot be loaded -- one
 //     hipMemcpyPeerAsync per device, enqueued on the PRODUCING device's stream so that each link carries its share as
 //     soon as its rank has finished;
-//   * rtk_tiles_unpermute on the first device writes the row-major image and the gamma / clamp / quantised bytes.
+//   * rtk_tiles_unpermute on the first device writes the row-major image and the gamma / clamp / quantised bytes;
+//   * rtk_render_multi_enqueue / rtk_multi_wait make that asynchronous with two frames in flight: gather and un-permute
+//     run on per-device transfer streams and on a second set of tile buffers while the next frame renders (an animation
+//     loop or a sequence of camera::render calls then gets what bench.py's pipelined RCCL ranks get).
 //
 // librccl.so is loaded with dlopen on first use: librtk_hip.so itself does not link it, single-GPU users never pay for it.
 #include <dlfcn.h>
@@ -59,22 +62,31 @@ RcclApi g_rccl;
 
 }  // namespace
 
+// Frames in flight (rtk_render_multi_enqueue): frame k uses buffer set k % kSlots -- its own compact tile buffers and its own
+// gather target -- so that the gather and the un-permute of frame k run while frame k + 1 renders.
+constexpr int kSlots = 2;
+
 struct rtk_multi {
     std::vector<int> devices;
     std::vector<rtk_ctx*> ctxs;
-    std::vector<hipStream_t> streams;
-    std::vector<hipEvent_t> done;     // device i's tiles have arrived on (or, for slot 0, were rendered on) the first device
+    std::vector<hipStream_t> streams;  // per device: the render stream ...
+    std::vector<hipStream_t> xfer;     // ... and the stream its share of the gather runs on (device 0: also the un-permute)
+    std::vector<hipEvent_t> rendered[kSlots];  // device i has rendered its tiles of the frame in this slot (render stream)
+    std::vector<hipEvent_t> arrived[kSlots];   // device i's tiles of that frame have arrived on the first device (xfer stream)
+    hipEvent_t released[kSlots] = {nullptr, nullptr};  // the frame in this slot has been un-permuted: its buffers may be rendered into again
+    bool slot_used[kSlots] = {false, false};
     std::vector<ncclComm_t> comms;    // empty: peer copies
-    // per-slot compact tile buffers (slot 0 renders straight into its part of `gathered`), and the gather target +
-    // the image buffers of rtk_render_multi on the first device; all grown on demand
-    std::vector<void*> compact;
-    std::vector<size_t> compact_bytes;
-    void* gathered = nullptr;
-    size_t gathered_bytes = 0;
+    // per device and slot: compact tile buffers (device 0 renders straight into its part of `gathered`); the gather targets
+    // and the image buffers of rtk_render_multi on the first device; all grown on demand
+    std::vector<void*> compact[kSlots];
+    std::vector<size_t> compact_bytes[kSlots];
+    void* gathered[kSlots] = {nullptr, nullptr};
+    size_t gathered_bytes[kSlots] = {0, 0};
     void* image = nullptr;
     size_t image_bytes = 0;
     uint8_t* rgb8 = nullptr;
     size_t rgb8_bytes = 0;
+    uint64_t frames_enqueued = 0;
 };
 
 namespace {
@@ -120,16 +132,24 @@ int rtk_init_multi(int n_devices, const int* devices, int gather_mode, rtk_multi
         if (rc != RTK_OK) return bail(rc);
         m->devices.push_back(devices[i]);
         m->ctxs.push_back(ctx);
-        hipStream_t st = nullptr;
-        hipEvent_t ev = nullptr;
+        hipStream_t st = nullptr, xf = nullptr;
         hipError_t e = hipSetDevice(devices[i]);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
         if (e == hipSuccess) m->streams.push_back(st);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-        if (e == hipSuccess) m->done.push_back(ev);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&xf, hipStreamNonBlocking);
+        if (e == hipSuccess) m->xfer.push_back(xf);
+        for (int s = 0; s < kSlots && e == hipSuccess; s++) {
+            hipEvent_t ev = nullptr;
+            e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) m->rendered[s].push_back(ev);
+            ev = nullptr;
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) m->arrived[s].push_back(ev);
+            if (i == 0 && e == hipSuccess) e = hipEventCreateWithFlags(&m->released[s], hipEventDisableTiming);
+            m->compact[s].push_back(nullptr);
+            m->compact_bytes[s].push_back(0);
+        }
         if (e != hipSuccess) return bail(fail(RTK_ERR_HIP, "rtk_init_multi: stream/event creation on device %d failed: %s", devices[i], hipGetErrorString(e)));
-        m->compact.push_back(nullptr);
-        m->compact_bytes.push_back(0);
     }
     // peer access towards the first device (the copies / RCCL use it where the topology offers it; failure is not fatal:
     // hipMemcpyPeerAsync then stages through the host)
@@ -170,16 +190,25 @@ int rtk_multi_destroy(rtk_multi* m) {
         if (c) (void)g_rccl.CommDestroy(c);
     for (size_t i = 0; i < m->ctxs.size(); i++) {
         (void)hipSetDevice(m->devices[i]);
-        if (i < m->streams.size() && m->streams[i]) {
-            (void)hipStreamSynchronize(m->streams[i]);
-            (void)hipStreamDestroy(m->streams[i]);
+        for (auto* list : {&m->streams, &m->xfer})
+            if (i < list->size() && (*list)[i]) (void)hipStreamSynchronize((*list)[i]);
+    }
+    for (size_t i = 0; i < m->ctxs.size(); i++) {
+        (void)hipSetDevice(m->devices[i]);
+        for (auto* list : {&m->streams, &m->xfer})
+            if (i < list->size() && (*list)[i]) (void)hipStreamDestroy((*list)[i]);
+        for (int s = 0; s < kSlots; s++) {
+            if (i < m->rendered[s].size() && m->rendered[s][i]) (void)hipEventDestroy(m->rendered[s][i]);
+            if (i < m->arrived[s].size() && m->arrived[s][i]) (void)hipEventDestroy(m->arrived[s][i]);
+            if (i < m->compact[s].size() && m->compact[s][i]) (void)hipFree(m->compact[s][i]);
         }
-        if (i < m->done.size() && m->done[i]) (void)hipEventDestroy(m->done[i]);
-        if (i < m->compact.size() && m->compact[i]) (void)hipFree(m->compact[i]);
     }
     if (!m->devices.empty()) {
         (void)hipSetDevice(m->devices[0]);
-        if (m->gathered) (void)hipFree(m->gathered);
+        for (int s = 0; s < kSlots; s++) {
+            if (m->released[s]) (void)hipEventDestroy(m->released[s]);
+            if (m->gathered[s]) (void)hipFree(m->gathered[s]);
+        }
         if (m->image) (void)hipFree(m->image);
         if (m->rgb8) (void)hipFree(m->rgb8);
     }
@@ -216,10 +245,20 @@ int rtk_multi_scene_upload_fast(rtk_multi* m, const rtk_scene_desc* scene, const
     return rc;
 }
 
-int rtk_render_multi_device(rtk_multi* m, const rtk_camera* cam, const rtk_render_opts* opts, void* d_linear, uint8_t* d_rgb8) {
-    if (!m || !cam || !opts) return fail(RTK_ERR_INVALID, "rtk_render_multi_device: null argument");
-    if (opts->count_work) return fail(RTK_ERR_INVALID, "rtk_render_multi_device: work counters are per device (use rtk_render_device)");
-    if (opts->real_mode != RTK_REAL_F64 && opts->real_mode != RTK_REAL_F32) return fail(RTK_ERR_INVALID, "rtk_render_multi_device: unknown real_mode %d", opts->real_mode);
+// Which buffer set frame `frame` (0, 1, 2, ...) uses and what its renders must wait for: host-only, the rule
+// rtk_render_multi_enqueue follows (exported so that the ordering can be tested where there is no GPU).
+// out[0] = slot, out[1] = 1 when the renders must first wait for the release of that slot by frame `frame - kSlots`.
+int rtk_multi_frame_plan(int64_t frame, int32_t out[2]) {
+    if (frame < 0 || !out) return fail(RTK_ERR_INVALID, "rtk_multi_frame_plan: bad argument");
+    out[0] = int32_t(frame % kSlots);
+    out[1] = frame >= kSlots ? 1 : 0;
+    return RTK_OK;
+}
+
+int rtk_render_multi_enqueue(rtk_multi* m, const rtk_camera* cam, const rtk_render_opts* opts, void* d_linear, uint8_t* d_rgb8) {
+    if (!m || !cam || !opts) return fail(RTK_ERR_INVALID, "rtk_render_multi_enqueue: null argument");
+    if (opts->count_work) return fail(RTK_ERR_INVALID, "rtk_render_multi_enqueue: work counters are per device (use rtk_render_device)");
+    if (opts->real_mode != RTK_REAL_F64 && opts->real_mode != RTK_REAL_F32) return fail(RTK_ERR_INVALID, "rtk_render_multi_enqueue: unknown real_mode %d", opts->real_mode);
     const int n = int(m->ctxs.size());
     if (n == 1 && m->comms.empty()) {  // one device: no tile buffers and no gather, the image directly (with RTK_GATHER_RCCL forced, one
                                        // device still goes through a 1-rank ncclGather: that is how the RCCL path is tested on a 1-GPU box)
@@ -228,61 +267,99 @@ int rtk_render_multi_device(rtk_multi* m, const rtk_camera* cam, const rtk_rende
         o.n_ranks = 1;
         o.stream = m->streams[0];
         const int rc1 = rtk_render_device(m->ctxs[0], cam, &o, d_linear, d_rgb8, nullptr);
-        return rc1 != RTK_OK ? rc1 : rtk::wait_with_progress(m->ctxs.data(), m->streams.data(), 1);
+        if (rc1 == RTK_OK) m->frames_enqueued++;
+        return rc1;
     }
     const size_t elem = opts->real_mode == RTK_REAL_F64 ? sizeof(double) : sizeof(float);
     const int64_t tpr = rtk_tiles_per_rank(cam->image_width, cam->image_height, n);
-    if (tpr <= 0) return fail(RTK_ERR_INVALID, "rtk_render_multi_device: bad image size");
+    if (tpr <= 0) return fail(RTK_ERR_INVALID, "rtk_render_multi_enqueue: bad image size");
     const size_t part = size_t(tpr) * 3 * RTK_TILE_PIXELS * elem;  // one device's compact buffer
+    int32_t plan[2];
+    (void)rtk_multi_frame_plan(int64_t(m->frames_enqueued), plan);
+    const int slot = plan[0];
     RTKM_HIP(hipSetDevice(m->devices[0]));
-    int rc = grow(&m->gathered, &m->gathered_bytes, part * size_t(n));
+    int rc = grow(&m->gathered[slot], &m->gathered_bytes[slot], part * size_t(n));
     if (rc != RTK_OK) return rc;
     for (int i = 1; i < n; i++) {
         RTKM_HIP(hipSetDevice(m->devices[size_t(i)]));
-        rc = grow(&m->compact[size_t(i)], &m->compact_bytes[size_t(i)], part);
+        rc = grow(&m->compact[slot][size_t(i)], &m->compact_bytes[slot][size_t(i)], part);
         if (rc != RTK_OK) return rc;
     }
-    // 1. every device renders its tiles; device 0 straight into its slot of the gather target (peer copies) or into the
-    //    same place as ncclGather's in-place send buffer
-    char* const gathered = static_cast<char*>(m->gathered);
+    // 1. every device renders its tiles on its render stream -- device 0 straight into its part of the gather target (for
+    //    ncclGather: the in-place send buffer of the root) -- once the frame that used this buffer set has been un-permuted
+    char* const gathered = static_cast<char*>(m->gathered[slot]);
     for (int i = 0; i < n; i++) {
+        RTKM_HIP(hipSetDevice(m->devices[size_t(i)]));
+        if (plan[1] && m->slot_used[slot]) RTKM_HIP(hipStreamWaitEvent(m->streams[size_t(i)], m->released[slot], 0));
         rtk_render_opts o = *opts;
         o.rank = i;
         o.n_ranks = n;
         o.stream = m->streams[size_t(i)];
         if (n == 1) o.variant |= 1 << 22;  // one device through the gather path (RCCL forced): still a tile buffer
-        void* target = i == 0 ? static_cast<void*>(gathered) : m->compact[size_t(i)];
+        void* target = i == 0 ? static_cast<void*>(gathered) : m->compact[slot][size_t(i)];
         rc = rtk_render_device(m->ctxs[size_t(i)], cam, &o, target, nullptr, nullptr);
         if (rc != RTK_OK) return rc;
+        RTKM_HIP(hipEventRecord(m->rendered[slot][size_t(i)], m->streams[size_t(i)]));
+        RTKM_HIP(hipStreamWaitEvent(m->xfer[size_t(i)], m->rendered[slot][size_t(i)], 0));
     }
-    // 2. the one gather
+    // 2. the one gather, on the transfer streams: the render streams are free for the next frame meanwhile
     if (!m->comms.empty()) {
         const ncclDataType_t type = opts->real_mode == RTK_REAL_F64 ? ncclDouble : ncclFloat;
         const size_t count = size_t(tpr) * 3 * RTK_TILE_PIXELS;
         ncclResult_t r = g_rccl.GroupStart();
-        for (int i = 0; i < n && r == ncclSuccess; i++) {
-            RTKM_HIP(hipSetDevice(m->devices[size_t(i)]));
-            const void* send = i == 0 ? static_cast<const void*>(gathered) : m->compact[size_t(i)];  // root: in place (its slot is slot 0)
-            r = g_rccl.Gather(send, gathered, count, type, 0, m->comms[size_t(i)], m->streams[size_t(i)]);
+        hipError_t he = hipSuccess;
+        for (int i = 0; i < n && r == ncclSuccess && he == hipSuccess; i++) {
+            he = hipSetDevice(m->devices[size_t(i)]);
+            if (he != hipSuccess) break;
+            const void* send = i == 0 ? static_cast<const void*>(gathered) : m->compact[slot][size_t(i)];  // root: in place (its part is part 0)
+            r = g_rccl.Gather(send, gathered, count, type, 0, m->comms[size_t(i)], m->xfer[size_t(i)]);
         }
-        const ncclResult_t r2 = g_rccl.GroupEnd();
-        if (r != ncclSuccess || r2 != ncclSuccess) return fail(RTK_ERR_HIP, "ncclGather failed: %s", g_rccl.GetErrorString(r != ncclSuccess ? r : r2));
+        const ncclResult_t r2 = g_rccl.GroupEnd();  // always: an open group would defer every later RCCL call of this thread
+        if (he != hipSuccess || r != ncclSuccess || r2 != ncclSuccess) {
+            for (int i = 0; i < n; i++) {  // what was launched is allowed to finish before the error is reported
+                (void)hipSetDevice(m->devices[size_t(i)]);
+                (void)hipStreamSynchronize(m->streams[size_t(i)]);
+            }
+            if (he != hipSuccess) return fail(RTK_ERR_HIP, "hipSetDevice failed inside the gather group: %s", hipGetErrorString(he));
+            return fail(RTK_ERR_HIP, "ncclGather failed: %s", g_rccl.GetErrorString(r != ncclSuccess ? r : r2));
+        }
     } else {
         for (int i = 1; i < n; i++) {
             RTKM_HIP(hipSetDevice(m->devices[size_t(i)]));
-            RTKM_HIP(hipMemcpyPeerAsync(gathered + part * size_t(i), m->devices[0], m->compact[size_t(i)], m->devices[size_t(i)], part, m->streams[size_t(i)]));
-            RTKM_HIP(hipEventRecord(m->done[size_t(i)], m->streams[size_t(i)]));
+            RTKM_HIP(hipMemcpyPeerAsync(gathered + part * size_t(i), m->devices[0], m->compact[slot][size_t(i)], m->devices[size_t(i)], part, m->xfer[size_t(i)]));
+            RTKM_HIP(hipEventRecord(m->arrived[slot][size_t(i)], m->xfer[size_t(i)]));
         }
         RTKM_HIP(hipSetDevice(m->devices[0]));
-        for (int i = 1; i < n; i++) RTKM_HIP(hipStreamWaitEvent(m->streams[0], m->done[size_t(i)], 0));
+        for (int i = 1; i < n; i++) RTKM_HIP(hipStreamWaitEvent(m->xfer[0], m->arrived[slot][size_t(i)], 0));
     }
-    // 3. compact tiles -> row-major image + bytes, on the first device (with RCCL the gather itself ordered stream 0)
+    // 3. compact tiles -> row-major image + bytes, on the first device's transfer stream (with RCCL the gather itself ordered
+    //    it; with peer copies the events above did), then the buffer set is released
     RTKM_HIP(hipSetDevice(m->devices[0]));
-    rc = rtk_tiles_unpermute(m->ctxs[0], cam->image_width, cam->image_height, n, opts->real_mode, gathered, d_linear, d_rgb8, m->streams[0]);
+    rc = rtk_tiles_unpermute(m->ctxs[0], cam->image_width, cam->image_height, n, opts->real_mode, gathered, d_linear, d_rgb8, m->xfer[0]);
     if (rc != RTK_OK) return rc;
-    rc = rtk::wait_with_progress(m->ctxs.data(), m->streams.data(), n);
+    RTKM_HIP(hipEventRecord(m->released[slot], m->xfer[0]));
+    m->slot_used[slot] = true;
+    m->frames_enqueued++;
+    return RTK_OK;
+}
+
+int rtk_multi_wait(rtk_multi* m) {
+    if (!m) return fail(RTK_ERR_INVALID, "rtk_multi_wait: null argument");
+    const int n = int(m->ctxs.size());
+    int rc = rtk::wait_with_progress(m->ctxs.data(), m->streams.data(), n);  // the renders (progress reports come from their counters)
+    for (int i = 0; i < n && rc == RTK_OK; i++) {                              // ... then the gathers and the un-permutes
+        hipError_t e = hipSetDevice(m->devices[size_t(i)]);
+        if (e == hipSuccess) e = hipStreamSynchronize(m->xfer[size_t(i)]);
+        if (e != hipSuccess) rc = fail(RTK_ERR_HIP, "rtk_multi_wait: hipStreamSynchronize failed: %s", hipGetErrorString(e));
+    }
     (void)hipSetDevice(m->devices[0]);
     return rc;
+}
+
+int rtk_render_multi_device(rtk_multi* m, const rtk_camera* cam, const rtk_render_opts* opts, void* d_linear, uint8_t* d_rgb8) {
+    if (!m || !cam || !opts) return fail(RTK_ERR_INVALID, "rtk_render_multi_device: null argument");
+    const int rc = rtk_render_multi_enqueue(m, cam, opts, d_linear, d_rgb8);
+    return rc != RTK_OK ? rc : rtk_multi_wait(m);
 }
 
 int rtk_render_multi(rtk_multi* m, const rtk_camera* cam, const rtk_render_opts* opts, double* h_linear, uint8_t* h_rgb8) {

@@ -18,7 +18,8 @@
 // (the RNG stream of a sample does not depend on the visiting order unless a
 // medium draws inside hit(), constant_medium.h:40 -- and media keep their place in
 // the reference's order, see ordered_group; only with opts.free_media_order are they
-// re-grouped too, parity then is statistical and rtk_optimize_info.exact says so).
+// re-grouped too, parity then is statistical and rtk_optimize_info.exact says so: 0 = statistical, 1 = identical in every
+// measurement but not provable (triangle scenes, below), 2 = proven bit-identical).
 // What changes: the work counters (fewer box tests).  Triangles: triangle::hit scales
 // its hit distance by a float reciprocal of a float determinant (triangle.h:72,77),
 // so an accepted hit can lie ~1e-7 of the travelled distance outside the triangle's
@@ -767,8 +768,14 @@ static int optimize_once(const rtk_scene_desc* scene, const rtk_optimize_opts* o
     if (info) {
         // Closest hits are preserved, exact ties are resolved by the reference's ranks (rtk_node.c) and a medium meets the
         // interval it meets in the reference (ordered_group), so the image is the reference order's bit for bit unless the
-        // caller asked for the free order of media; has_triangles flags the one caveat left (see rtk.h)
-        info->exact = (op.has_media && !op.keep_media_order) ? 0 : 1;
+        // caller asked for the free order of media: exact = 2, PROVEN.  Triangles are the one caveat (header of this file,
+        // rtk.h): triangle::hit scales t by a float reciprocal (triangle.h:72,77), so the REFERENCE's own exact boxes can
+        // cull a hit its triangle::hit would accept, depending on its visiting order -- no other hierarchy can reproduce
+        // that, and nothing here can rule it out for a given scene.  Identical in every measurement (C4: 0 of 5.3e8
+        // samples), but that is a measurement: exact = 1, EMPIRICAL.  Callers that promise "the image never depends on
+        // the order" (camera::auto_order) take the fast order on 2 only; bench.py takes it on 1 as well and verifies the
+        // claim in the same run (both orders rendered, digests compared).
+        info->exact = (op.has_media && !op.keep_media_order) ? 0 : (op.has_triangles ? 1 : 2);
         info->has_media = op.has_media ? 1 : 0;
         info->n_ordered_items = op.n_ordered;
         info->has_triangles = op.has_triangles ? 1 : 0;
@@ -787,7 +794,10 @@ void rtk_scene_optimized_free(rtk_scene_desc* scene) { delete reinterpret_cast<H
 // triangle 80, quad 144, every other record 32) the upload would compile from `d`, materials included -- the quantity
 // that decides whether the f64 kernels can keep the whole program in one CU's LDS (160 KB).  Mirrors the compiler's walk
 // (rtk_api.cpp): a shared subtree counts once per use; a sphere-bounded medium is one 48-byte record.
-static size_t compact_program_bytes(const rtk_scene_desc& d) {
+// `mixed_layout`: the scene is one the upload gives the MIXED program instead (sphere-only scenes: 32-byte units -- a
+// stationary sphere takes 64 bytes there, a moving one 96); sizing such a scene with the COMPACT figures accepted
+// hierarchies of ~1 700-2 000 spheres whose MIXED program no longer fits LDS.
+static size_t compact_program_bytes(const rtk_scene_desc& d, bool mixed_layout = false) {
     size_t bytes = 32 /* OP_END */ + size_t(d.n_materials) * 48;
     std::vector<std::pair<int32_t, int>> stack{{d.root, 0}};
     size_t guard = 0;
@@ -799,7 +809,7 @@ static size_t compact_program_bytes(const rtk_scene_desc& d) {
         switch (n.kind) {
             case RTK_NODE_SPHERE: {
                 const bool moving = n.a >= 0 && n.a < d.n_spheres && (d.spheres[n.a].center_dir.x != 0 || d.spheres[n.a].center_dir.y != 0 || d.spheres[n.a].center_dir.z != 0);
-                bytes += moving ? 80 : 48;
+                bytes += mixed_layout ? (moving ? 96 : 64) : (moving ? 80 : 48);
                 break;
             }
             case RTK_NODE_QUAD: bytes += 144; break;
@@ -860,6 +870,18 @@ static void slot_program_counts(const rtk_scene_desc& d, size_t& n_slots, size_t
     }
 }
 
+// Will the upload compile the MIXED program for this scene (rtk_api.cpp upload_scene: want_mixed)?  Spheres only, no instance
+// transforms, media or point lights, lambertian / metal / dielectric materials with solid colours.
+static bool gets_mixed_program(const rtk_scene_desc& d) {
+    if (d.n_quads > 0 || d.n_triangles > 0 || d.n_media > 0 || d.n_translates > 0 || d.n_rotates > 0 || d.n_lights > 0) return false;
+    for (int32_t i = 0; i < d.n_materials; i++) {
+        const rtk_material& m = d.materials[i];
+        if (m.kind != RTK_MAT_LAMBERTIAN && m.kind != RTK_MAT_METAL && m.kind != RTK_MAT_DIELECTRIC) return false;
+        if (m.kind == RTK_MAT_LAMBERTIAN && (m.texture < 0 || m.texture >= d.n_textures || d.textures[m.texture].kind != RTK_TEX_SOLID)) return false;
+    }
+    return true;
+}
+
 // With opts->prim_cost_scale left at 0 ("automatic") the price of a primitive test relative to a slab test is chosen by
 // where the f64 kernels will find the traversal program (rtk_api.cpp / rtk_trace.hip):
 //  * a scene of spheres and triangles is re-grouped with primitive tests priced 1.5x dearer -- more, tighter boxes and fewer
@@ -884,6 +906,7 @@ int rtk_scene_optimize(const rtk_scene_desc* scene, const rtk_optimize_opts* opt
     const double* kScales = scene->n_quads == 0 ? kScalesNoQuads : kScalesQuads;
     const int n_scales = scene->n_quads == 0 ? int(sizeof kScalesNoQuads / sizeof kScalesNoQuads[0]) : int(sizeof kScalesQuads / sizeof kScalesQuads[0]);
     const bool full_feature = scene->n_media > 0 || scene->n_translates > 0 || scene->n_rotates > 0;  // only those kernels have the hot/cold form
+    const bool mixed_layout = gets_mixed_program(*scene);
     rtk_scene_desc* fallback = nullptr;  // the first hierarchy whose slot program at least keeps its boxes in LDS
     rtk_optimize_info fallback_info;
     for (int k = 0; k < n_scales; k++) {
@@ -895,7 +918,7 @@ int rtk_scene_optimize(const rtk_scene_desc* scene, const rtk_optimize_opts* opt
             if (fallback) rtk_scene_optimized_free(fallback);
             return rc;
         }
-        bool accept = compact_program_bytes(*candidate) <= budget;
+        bool accept = compact_program_bytes(*candidate, mixed_layout) <= budget;  // sized in the layout the upload will use
         if (!accept && kScales[k] <= 1.0 && full_feature) {
             // the hot part (rtk_api.cpp compiles the program: exact), and the Perlin tables behind it: book-2's noise sphere
             // costs 4 % of the frame when perlin::turb gathers from memory instead

@@ -33,6 +33,15 @@ template <typename real>
 hipError_t launch_debug_hit(const SceneView<real>& sc, int n, const double* d_rays, const uint32_t* d_keys, double* d_out, unsigned long long* d_draws,
                             hipStream_t stream);
 
+// Known-answer helpers for the shading side: shade_surface, texture_value and begin_sample on caller-supplied inputs.
+template <typename real>
+hipError_t launch_debug_scatter(const SceneView<real>& sc, int n, const int32_t* d_mat, const double* d_ray, const double* d_rec, const uint32_t* d_keys, double* d_out,
+                                unsigned long long* d_draws, hipStream_t stream);
+template <typename real>
+hipError_t launch_debug_texture(const SceneView<real>& sc, int n, const int32_t* d_tex, const double* d_uvp, double* d_out, unsigned long long* d_work, hipStream_t stream);
+template <typename real>
+hipError_t launch_debug_get_ray(const CameraRec<real>& cam, uint32_t seed, int n, const int32_t* d_ijs, double* d_out, unsigned long long* d_draws, hipStream_t stream);
+
 template <typename real>
 hipError_t launch_unpermute(const void* gathered, int width, int height, int n_ranks, long long tiles_per_rank, void* out_linear, uint8_t* out_rgb8,
                             hipStream_t stream);

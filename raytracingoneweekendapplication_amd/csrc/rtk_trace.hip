@@ -1164,26 +1164,15 @@ RTK_DEV void begin_sample(Lane<real>& L, const CameraRec<real>& cam, int i, int 
 template <uint32_t FEAT>
 constexpr bool kNoRadianceState = (FEAT & (F_LIGHTS | F_EXOTIC_MAT)) == 0;
 
-// The traversal program ran to OP_END: the body of ray_color after world.hit
-// (Camera.txt:211-237), iteratively (radiance = sum of throughput * emission).
-// Returns true when the sample's path has ended.
-// `hit_rec` = the record of the closest hit (program + L.best_pc; anything when there is none).
-template <typename real, uint32_t FEAT, bool COUNT, typename ProgT>
-RTK_DEV bool shade(Lane<real>& L, const ProgT* __restrict__ hit_rec, const SceneView<real>& sc, const MaterialRec<real>* __restrict__ mats,
-                   const CameraRec<real>& cam, Counters<COUNT>& cnt RTK_SHADE_PROF_PARAM) {
+// material::scatter / emitted on a finished hit record (material.h:22-172) and the rest of ray_color's body
+// (Camera.txt:216-237): what shade() runs after it has built the record -- and what the known-answer entry point
+// rtk_debug_scatter runs on caller-supplied records.  Returns true when the sample's path has ended.
+template <typename real, uint32_t FEAT, int FORCE_KIND = -1, bool COUNT>
+RTK_DEV bool shade_surface(Lane<real>& L, const Surface<real>& sf, const SceneView<real>& sc, const MaterialRec<real>* __restrict__ mats,
+                           Counters<COUNT>& cnt RTK_SHADE_PROF_PARAM) {
     RTK_SHADE_PROF_BEGIN
-    if (L.best_pc == kNoHit) {  // Camera.txt:211-213
-        if constexpr (kNoRadianceState<FEAT>) L.sum = L.sum + L.throughput * ld3(cam.background);  // = sum + (0 + throughput * background), the same bits
-        else L.radiance = L.radiance + L.throughput * ld3(cam.background);
-        return true;
-    }
-    cnt.inc(C_SURFACE);
-    RTK_SHADE_PROF(2)
-    Surface<real> sf;
-    if constexpr (std::is_same_v<ProgT, MixedHead>) make_surface_mixed(hit_rec, 0u, L.best_t, L.ro, L.rd, L.tm, sf);  // lean MIXED program
-    else make_surface<real, FEAT>(hit_rec, sc, mats, 0u, L.best_t, L.ro, L.rd, L.tm, sf);                             // slot or COMPACT program
-    RTK_SHADE_PROF(0)
     const MaterialRec<real>& m = mats[sf.material];
+    const int mkind = FORCE_KIND >= 0 ? FORCE_KIND : m.kind;  // (FORCE_KIND: the instruction-cost probes compile one material's path alone, tools/isa_costs.py)
     const V3<real> rd = L.rd;
 
     V3<real> attenuation, next_d;
@@ -1199,17 +1188,17 @@ RTK_DEV bool shade(Lane<real>& L, const ProgT* __restrict__ hit_rec, const Scene
     constexpr bool kHoist = (FEAT & F_XFORM) == 0;
     V3<real> ruv = mk(real(0), real(0), real(0)), unit_in = rd;
     if constexpr (kHoist) {
-        if (m.kind == RTK_MAT_LAMBERTIAN || m.kind == RTK_MAT_METAL) ruv = random_unit_vector<real>(L.rng, cnt);
-        if (m.kind == RTK_MAT_METAL) unit_in = reflect(rd, sf.normal);
-        if (m.kind == RTK_MAT_METAL || m.kind == RTK_MAT_DIELECTRIC || ((FEAT & F_EXOTIC_MAT) && m.kind == RTK_MAT_SPECULAR)) unit_in = unit_vector(unit_in);
+        if (mkind == RTK_MAT_LAMBERTIAN || mkind == RTK_MAT_METAL) ruv = random_unit_vector<real>(L.rng, cnt);
+        if (mkind == RTK_MAT_METAL) unit_in = reflect(rd, sf.normal);
+        if (mkind == RTK_MAT_METAL || mkind == RTK_MAT_DIELECTRIC || ((FEAT & F_EXOTIC_MAT) && mkind == RTK_MAT_SPECULAR)) unit_in = unit_vector(unit_in);
     }
-    if (m.kind == RTK_MAT_LAMBERTIAN) {  // material.h:29-38
+    if (mkind == RTK_MAT_LAMBERTIAN) {  // material.h:29-38
         if constexpr (!kHoist) ruv = random_unit_vector<real>(L.rng, cnt);
         V3<real> dir = sf.normal + ruv;
         if (near_zero(dir)) dir = sf.normal;
         next_d = dir;
         attenuation = material_color<real, FEAT>(sc, m, sf.u, sf.v, sf.p, cnt);
-    } else if (!(FEAT & F_MATTE) && m.kind == RTK_MAT_METAL) {  // material.h:82-88
+    } else if (!(FEAT & F_MATTE) && mkind == RTK_MAT_METAL) {  // material.h:82-88
         if constexpr (!kHoist) {
             ruv = random_unit_vector<real>(L.rng, cnt);
             unit_in = unit_vector(reflect(rd, sf.normal));
@@ -1218,7 +1207,7 @@ RTK_DEV bool shade(Lane<real>& L, const ProgT* __restrict__ hit_rec, const Scene
         next_d = unit_in + fuzz;
         attenuation = ld3(m.albedo);
         scattered = dot(next_d, sf.normal) > real(0);
-    } else if (!(FEAT & F_MATTE) && m.kind == RTK_MAT_DIELECTRIC) {  // material.h:47-65
+    } else if (!(FEAT & F_MATTE) && mkind == RTK_MAT_DIELECTRIC) {  // material.h:47-65
         attenuation = mk(real(1), real(1), real(1));
         // 1/refraction_index and Schlick's r0^2 for both faces are per-material constants: computed once at upload,
         // in double, by the same expressions (material.h:50,71-72)
@@ -1241,10 +1230,10 @@ RTK_DEV bool shade(Lane<real>& L, const ProgT* __restrict__ hit_rec, const Scene
             reflect_it = refl > rnd<real>(L.rng, cnt);
         }
         next_d = reflect_it ? reflect(unit_d, sf.normal) : refract(unit_d, sf.normal, ri);
-    } else if ((FEAT & F_EXOTIC_MAT) && !(FEAT & F_MATTE) && m.kind == RTK_MAT_ISOTROPIC) {  // material.h:129-134
+    } else if ((FEAT & F_EXOTIC_MAT) && !(FEAT & F_MATTE) && mkind == RTK_MAT_ISOTROPIC) {  // material.h:129-134
         next_d = random_unit_vector<real>(L.rng, cnt);
         attenuation = material_color<real, FEAT>(sc, m, sf.u, sf.v, sf.p, cnt);
-    } else if ((FEAT & F_EXOTIC_MAT) && !(FEAT & F_MATTE) && m.kind == RTK_MAT_SPECULAR) {  // material.h:145-167
+    } else if ((FEAT & F_EXOTIC_MAT) && !(FEAT & F_MATTE) && mkind == RTK_MAT_SPECULAR) {  // material.h:145-167
         if constexpr (!kHoist) unit_in = unit_vector(rd);
         const V3<real> unit_d = unit_in;
         const V3<real> refl = reflect(unit_d, sf.normal);
@@ -1274,6 +1263,28 @@ RTK_DEV bool shade(Lane<real>& L, const ProgT* __restrict__ hit_rec, const Scene
     L.depth -= 1;
     RTK_SHADE_PROF(3)
     return L.depth <= 0;  // Camera.txt:205-206: the next ray_color call returns black
+}
+
+// The traversal program ran to OP_END: the body of ray_color after world.hit
+// (Camera.txt:211-237), iteratively (radiance = sum of throughput * emission).
+// Returns true when the sample's path has ended.
+// `hit_rec` = the record of the closest hit (program + L.best_pc; anything when there is none).
+template <typename real, uint32_t FEAT, bool COUNT, typename ProgT>
+RTK_DEV bool shade(Lane<real>& L, const ProgT* __restrict__ hit_rec, const SceneView<real>& sc, const MaterialRec<real>* __restrict__ mats,
+                   const CameraRec<real>& cam, Counters<COUNT>& cnt RTK_SHADE_PROF_PARAM) {
+    RTK_SHADE_PROF_BEGIN
+    if (L.best_pc == kNoHit) {  // Camera.txt:211-213
+        if constexpr (kNoRadianceState<FEAT>) L.sum = L.sum + L.throughput * ld3(cam.background);  // = sum + (0 + throughput * background), the same bits
+        else L.radiance = L.radiance + L.throughput * ld3(cam.background);
+        return true;
+    }
+    cnt.inc(C_SURFACE);
+    RTK_SHADE_PROF(2)
+    Surface<real> sf;
+    if constexpr (std::is_same_v<ProgT, MixedHead>) make_surface_mixed(hit_rec, 0u, L.best_t, L.ro, L.rd, L.tm, sf);  // lean MIXED program
+    else make_surface<real, FEAT>(hit_rec, sc, mats, 0u, L.best_t, L.ro, L.rd, L.tm, sf);                             // slot or COMPACT program
+    RTK_SHADE_PROF(0)
+    return shade_surface<real, FEAT>(L, sf, sc, mats, cnt RTK_SHADE_PROF_ARG);
 }
 
 RTK_DEV uint8_t to_byte(double x) {  // Camera.txt:29-34,77-83
@@ -2114,12 +2125,27 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
 #endif
             RTK_PROF_MARK(7, 1, popcount64(__ballot(alive)))
         } else {
-            if (m_oth >> lane & 1ull) {
-                if constexpr (MIXED && !COMPACT) step_other_mixed<kPcUnit>(L, rec_at(L.pc), cnt, tie, extent);
-                else step_other<real, FEAT, COUNT>(L, prog + L.pc, sc, cnt, tie, extent);
-                L.kind = kind_of(L.pc);
-            }
-            RTK_PROF_MARK(4, 1, n_oth)
+            // Rare records come in short runs too -- book 2's two media are neighbours in the program, an instance is entered
+            // and left through two chain switches around a small subtree: stay (up to RTK_OTHER_LOOP steps) while at least half
+            // of the starters still sit on a rare record, instead of paying a vote for each.
+#ifndef RTK_OTHER_LOOP
+#define RTK_OTHER_LOOP 4
+#endif
+            bool mine = (m_oth >> lane & 1ull) != 0ull;
+            [[maybe_unused]] const int keep_oth = (n_oth + 1) >> 1;
+            [[maybe_unused]] int rounds = 0, n_mine = 0;
+            do {
+                if (mine) {
+                    if constexpr (MIXED && !COMPACT) step_other_mixed<kPcUnit>(L, rec_at(L.pc), cnt, tie, extent);
+                    else step_other<real, FEAT, COUNT>(L, prog + L.pc, sc, cnt, tie, extent);
+                    const uint32_t k2 = kind_of(L.pc);
+                    L.kind = k2;
+                    mine = k2 != L.box_kind && k2 != OP_SPHERE && k2 != OP_END && !((FEAT & F_QUAD) && k2 == OP_QUAD) && !((FEAT & F_TRI) && k2 == OP_TRI);
+                }
+                RTK_PROF_MARK(4, 1, n_oth)
+                if constexpr (RTK_OTHER_LOOP <= 1 || (MIXED && !COMPACT)) break;
+                n_mine = popcount64(__ballot(mine));
+            } while (n_mine >= keep_oth && ++rounds < RTK_OTHER_LOOP);
         }
     }
     RTK_PROF_FLUSH
@@ -2184,6 +2210,82 @@ __global__ __launch_bounds__(256) void rtk_debug_hit_kernel(SceneView<real> sc, 
         o[9] = double(sf.u); o[10] = double(sf.v);
         o[11] = double(sf.material);
     }
+    draws[gid] = cnt.c[C_RNG];
+}
+
+// Known-answer entry points for the shading side (tests): the very device functions the render kernel executes --
+// shade_surface (material::scatter / emitted, material.h:22-172), texture_value (texture.h:20-120, perlin.h:14-50) and
+// begin_sample (get_ray, Camera.txt:177-200) -- on caller-supplied inputs, one lane per case.
+//   scatter: mat[n]; ray[n][7] = origin, direction, time; rec[n][11] = t, p(3), normal(3), front_face, u, v, -;
+//            out[n][14] = scattered?, scattered ray origin(3) direction(3), attenuation(3), time, emitted(3)
+template <typename real>
+__global__ __launch_bounds__(256) void rtk_debug_scatter_kernel(SceneView<real> sc, int n, const int32_t* __restrict__ mat, const double* __restrict__ ray,
+                                                                 const double* __restrict__ rec, const uint32_t* __restrict__ keys, double* __restrict__ out,
+                                                                 unsigned long long* __restrict__ draws) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n) return;
+    sc.n_lights = 0;  // get_lighting (Camera.txt:228) belongs to ray_color, not to scatter()
+    Counters<true> cnt;
+    cnt.clear();
+    const double* r = ray + size_t(gid) * 7;
+    const double* h = rec + size_t(gid) * 11;
+    Lane<real> L;
+    L.ro = mk(real(r[0]), real(r[1]), real(r[2]));
+    L.rd = mk(real(r[3]), real(r[4]), real(r[5]));
+    L.tm = real(r[6]);
+    L.rng = pcg_hash(keys[gid * 3 + 1] + pcg_hash(keys[gid * 3 + 2] + pcg_hash(keys[gid * 3])));
+    L.throughput = mk(real(1), real(1), real(1));
+    L.radiance = mk(real(0), real(0), real(0));
+    L.sum = mk(real(0), real(0), real(0));
+    L.depth = 1 << 20;
+    Surface<real> sf;
+    sf.p = mk(real(h[1]), real(h[2]), real(h[3]));
+    sf.normal = mk(real(h[4]), real(h[5]), real(h[6]));
+    sf.front_face = h[7] != 0.0;
+    sf.u = real(h[8]);
+    sf.v = real(h[9]);
+    sf.material = mat[gid];
+    const bool ended = shade_surface<real, kFeatAll>(L, sf, sc, sc.materials, cnt);
+    double* o = out + size_t(gid) * 14;
+    o[0] = ended ? 0.0 : 1.0;
+    o[1] = double(L.ro.x); o[2] = double(L.ro.y); o[3] = double(L.ro.z);
+    o[4] = double(L.rd.x); o[5] = double(L.rd.y); o[6] = double(L.rd.z);
+    o[7] = double(L.throughput.x); o[8] = double(L.throughput.y); o[9] = double(L.throughput.z);
+    o[10] = double(L.tm);
+    o[11] = double(L.radiance.x); o[12] = double(L.radiance.y); o[13] = double(L.radiance.z);
+    draws[gid] = cnt.c[C_RNG];
+}
+//   texture: tex[n]; uvp[n][5] = u, v, p(3); out[n][3] = texture::value(u, v, p); work[n][2] = perlin::noise calls, texel fetches
+template <typename real>
+__global__ __launch_bounds__(256) void rtk_debug_texture_kernel(SceneView<real> sc, int n, const int32_t* __restrict__ tex, const double* __restrict__ uvp,
+                                                                 double* __restrict__ out, unsigned long long* __restrict__ work) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n) return;
+    Counters<true> cnt;
+    cnt.clear();
+    const double* q = uvp + size_t(gid) * 5;
+    const V3<real> c = texture_value(sc, tex[gid], real(q[0]), real(q[1]), mk(real(q[2]), real(q[3]), real(q[4])), cnt);
+    out[size_t(gid) * 3] = double(c.x);
+    out[size_t(gid) * 3 + 1] = double(c.y);
+    out[size_t(gid) * 3 + 2] = double(c.z);
+    work[size_t(gid) * 2] = cnt.c[C_NOISE];
+    work[size_t(gid) * 2 + 1] = cnt.c[C_TEXEL];
+}
+//   get_ray: ijs[n][3] = pixel i, j, sample; out[n][7] = origin, direction, time
+template <typename real>
+__global__ __launch_bounds__(256) void rtk_debug_get_ray_kernel(CameraRec<real> cam, uint32_t seed, int n, const int32_t* __restrict__ ijs, double* __restrict__ out,
+                                                                 unsigned long long* __restrict__ draws) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n) return;
+    Counters<true> cnt;
+    cnt.clear();
+    Lane<real> L;
+    L.s = ijs[gid * 3 + 2];
+    begin_sample(L, cam, ijs[gid * 3], ijs[gid * 3 + 1], pcg_hash(seed), cnt);
+    double* o = out + size_t(gid) * 7;
+    o[0] = double(L.ro.x); o[1] = double(L.ro.y); o[2] = double(L.ro.z);
+    o[3] = double(L.rd.x); o[4] = double(L.rd.y); o[5] = double(L.rd.z);
+    o[6] = double(L.tm);
     draws[gid] = cnt.c[C_RNG];
 }
 
@@ -2591,6 +2693,34 @@ template hipError_t launch_debug_hit<double>(const SceneView<double>&, int, cons
 template hipError_t launch_debug_hit<float>(const SceneView<float>&, int, const double*, const uint32_t*, double*, unsigned long long*, hipStream_t);
 
 template <typename real>
+hipError_t launch_debug_scatter(const SceneView<real>& sc, int n, const int32_t* d_mat, const double* d_ray, const double* d_rec, const uint32_t* d_keys, double* d_out,
+                                unsigned long long* d_draws, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    rtk_debug_scatter_kernel<real><<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(sc, n, d_mat, d_ray, d_rec, d_keys, d_out, d_draws);
+    return hipGetLastError();
+}
+template hipError_t launch_debug_scatter<double>(const SceneView<double>&, int, const int32_t*, const double*, const double*, const uint32_t*, double*, unsigned long long*, hipStream_t);
+template hipError_t launch_debug_scatter<float>(const SceneView<float>&, int, const int32_t*, const double*, const double*, const uint32_t*, double*, unsigned long long*, hipStream_t);
+
+template <typename real>
+hipError_t launch_debug_texture(const SceneView<real>& sc, int n, const int32_t* d_tex, const double* d_uvp, double* d_out, unsigned long long* d_work, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    rtk_debug_texture_kernel<real><<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(sc, n, d_tex, d_uvp, d_out, d_work);
+    return hipGetLastError();
+}
+template hipError_t launch_debug_texture<double>(const SceneView<double>&, int, const int32_t*, const double*, double*, unsigned long long*, hipStream_t);
+template hipError_t launch_debug_texture<float>(const SceneView<float>&, int, const int32_t*, const double*, double*, unsigned long long*, hipStream_t);
+
+template <typename real>
+hipError_t launch_debug_get_ray(const CameraRec<real>& cam, uint32_t seed, int n, const int32_t* d_ijs, double* d_out, unsigned long long* d_draws, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    rtk_debug_get_ray_kernel<real><<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(cam, seed, n, d_ijs, d_out, d_draws);
+    return hipGetLastError();
+}
+template hipError_t launch_debug_get_ray<double>(const CameraRec<double>&, uint32_t, int, const int32_t*, double*, unsigned long long*, hipStream_t);
+template hipError_t launch_debug_get_ray<float>(const CameraRec<float>&, uint32_t, int, const int32_t*, double*, unsigned long long*, hipStream_t);
+
+template <typename real>
 hipError_t launch_unpermute(const void* gathered, int width, int height, int n_ranks, long long tiles_per_rank, void* out_linear, uint8_t* out_rgb8,
                             hipStream_t stream) {
     const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
@@ -2602,5 +2732,64 @@ hipError_t launch_unpermute(const void* gathered, int width, int height, int n_r
 }
 template hipError_t launch_unpermute<double>(const void*, int, int, int, long long, void*, uint8_t*, hipStream_t);
 template hipError_t launch_unpermute<float>(const void*, int, int, int, long long, void*, uint8_t*, hipStream_t);
+
+#ifdef RTK_ISA_PROBES
+// Instruction-cost probes (tools/isa_costs.py; never part of the product build): one kernel per unit of work of the lean
+// MIXED kernel family (what bench.py times on C2), each loading a lane's state from memory, running ONE step through the
+// product's own step function and storing the state back.  The tool counts the VALU instructions of each probe by class in the
+// ISA and subtracts the empty probe: what is left is the instruction cost of that unit of work when a whole wave executes it
+// once -- the per-unit figures behind bench.py's roofline.work_frac (work counters x these costs / 64 lanes / SIMD-cycles
+// available: a fraction that executing MORE instructions cannot raise).
+constexpr uint32_t kProbeFeat = kFeatLean | uint32_t(F_F32_BOX);
+enum ProbeKind : int { PROBE_EMPTY, PROBE_BOX, PROBE_SPHERE, PROBE_SEGMENT, PROBE_SAMPLE, PROBE_MISS, PROBE_LAMBERTIAN, PROBE_METAL, PROBE_DIELECTRIC, PROBE_PARTIAL };
+template <int KIND>
+__global__ __launch_bounds__(1024) void rtk_isa_probe(Lane<double>* __restrict__ lanes, const MixedHead* __restrict__ prog, SceneView<double> sc,
+                                                       const CameraRec<double>* __restrict__ cam_ptr, double* __restrict__ partial, float extent) {
+    const int gid = blockIdx.x * 1024 + threadIdx.x;
+    Lane<double> L = lanes[gid];
+    Counters<false> cnt;
+    const NoTie tie{};
+    const MixedHead* rec = reinterpret_cast<const MixedHead*>(reinterpret_cast<const unsigned char*>(prog) + L.pc);
+    if constexpr (KIND == PROBE_BOX) {  // one box step: the slab test on the record in registers, then the next record and its kind
+        MixedHead cur = *rec;
+        step_box32_ch(L, cur, cnt);
+        cur = *reinterpret_cast<const MixedHead*>(reinterpret_cast<const unsigned char*>(prog) + L.pc);
+        L.kind = cur.kind_payload & 15u;
+        L.oi32_lo.x = cur.f(0);  // (keeps the fetched record alive, as the next step's slab test does)
+    } else if constexpr (KIND == PROBE_SPHERE) {
+        MixedHead cur = *rec;
+        step_sphere_mixed<kChPcUnit>(L, cur, rec, cnt, tie, extent);
+        cur = *reinterpret_cast<const MixedHead*>(reinterpret_cast<const unsigned char*>(prog) + L.pc);
+        L.kind = cur.kind_payload & 15u;
+        L.oi32_lo.x = cur.f(0);
+    } else if constexpr (KIND == PROBE_SEGMENT) {
+        begin_segment<false, true, 1>(L, cnt, extent);
+        L.kind = rec->kind_payload & 15u;
+    } else if constexpr (KIND == PROBE_SAMPLE) {
+        begin_sample(L, *cam_ptr, int(L.segs), L.depth, pcg_hash(L.best_pc), cnt);
+    } else if constexpr (KIND == PROBE_MISS) {
+        L.sum = L.sum + L.throughput * ld3(cam_ptr->background);
+    } else if constexpr (KIND == PROBE_LAMBERTIAN || KIND == PROBE_METAL || KIND == PROBE_DIELECTRIC) {
+        Surface<double> sf;
+        make_surface_mixed(rec, 0u, L.best_t, L.ro, L.rd, L.tm, sf);
+        constexpr int kMat = KIND == PROBE_LAMBERTIAN ? int(RTK_MAT_LAMBERTIAN) : (KIND == PROBE_METAL ? int(RTK_MAT_METAL) : int(RTK_MAT_DIELECTRIC));
+        const bool ended = shade_surface<double, kProbeFeat, kMat>(L, sf, sc, sc.materials, cnt);
+        L.kind = ended ? 1u : 0u;
+    } else if constexpr (KIND == PROBE_PARTIAL) {
+        store_partial(partial, int(L.segs), L.depth, L.sum);
+    }
+    lanes[gid] = L;
+}
+template __global__ void rtk_isa_probe<PROBE_EMPTY>(Lane<double>*, const MixedHead*, SceneView<double>, const CameraRec<double>*, double*, float);
+template __global__ void rtk_isa_probe<PROBE_BOX>(Lane<double>*, const MixedHead*, SceneView<double>, const CameraRec<double>*, double*, float);
+template __global__ void rtk_isa_probe<PROBE_SPHERE>(Lane<double>*, const MixedHead*, SceneView<double>, const CameraRec<double>*, double*, float);
+template __global__ void rtk_isa_probe<PROBE_SEGMENT>(Lane<double>*, const MixedHead*, SceneView<double>, const CameraRec<double>*, double*, float);
+template __global__ void rtk_isa_probe<PROBE_SAMPLE>(Lane<double>*, const MixedHead*, SceneView<double>, const CameraRec<double>*, double*, float);
+template __global__ void rtk_isa_probe<PROBE_MISS>(Lane<double>*, const MixedHead*, SceneView<double>, const CameraRec<double>*, double*, float);
+template __global__ void rtk_isa_probe<PROBE_LAMBERTIAN>(Lane<double>*, const MixedHead*, SceneView<double>, const CameraRec<double>*, double*, float);
+template __global__ void rtk_isa_probe<PROBE_METAL>(Lane<double>*, const MixedHead*, SceneView<double>, const CameraRec<double>*, double*, float);
+template __global__ void rtk_isa_probe<PROBE_DIELECTRIC>(Lane<double>*, const MixedHead*, SceneView<double>, const CameraRec<double>*, double*, float);
+template __global__ void rtk_isa_probe<PROBE_PARTIAL>(Lane<double>*, const MixedHead*, SceneView<double>, const CameraRec<double>*, double*, float);
+#endif  // RTK_ISA_PROBES
 
 }  // namespace rtk

@@ -118,16 +118,21 @@ public:
     rtk_progress_fn progress = nullptr;
     void* progress_user = nullptr;
     // Visiting order of the hierarchy.  auto_order (default): the fast order of rtk_scene_upload_fast (same primitives, SAH
-    // grouping, ~half the aabb::hit calls) whenever it is bit-identical to the reference's bvh_node order -- which it is
-    // unless free_media_order is set -- and the reference order otherwise, so the image never depends on this choice.
+    // grouping, ~half the aabb::hit calls) whenever it is PROVEN bit-identical to the reference's bvh_node order
+    // (rtk_optimize_info.exact == 2: every scene without triangles, unless free_media_order is set) and the reference order
+    // otherwise, so the image never depends on this choice.  Triangle scenes are identical in every measurement but not
+    // provably so (exact == 1: triangle.h:72,77 scales t by a float reciprocal): auto_order takes the fast order for them
+    // only when accept_empirical_order is set; order = fast_order always takes it.
     enum visiting_order { reference_order = 0, fast_order = 1, auto_order = 2 };
     int order = auto_order;
+    bool accept_empirical_order = false;
     // A constant_medium draws a random number inside hit() (constant_medium.h:40); by default media keep their place in the
     // reference's order (rtk_optimize_opts.free_media_order = 0).  true: media are re-grouped as well -- a little faster,
     // same estimator, but another image than the reference order's (auto_order then stays on the reference order).
     bool free_media_order = false;
     bool used_fast_order = false;      // set by render(): which order the last render used ...
-    bool fast_order_exact = false;     // ... and whether the fast order is bit-identical for this scene
+    bool fast_order_exact = false;     // ... whether the fast order is bit-identical for this scene (proven or measured) ...
+    int fast_order_exactness = 0;      // ... and which: rtk_optimize_info.exact (2 proven, 1 empirical, 0 statistical)
     double last_render_ms = 0;         // device render time of the last render()
 
     // Camera.txt:136-175.
@@ -185,6 +190,7 @@ public:
         if (rc != RTK_OK) return rc;
         used_fast_order = false;
         fast_order_exact = false;
+        fast_order_exactness = 0;
         if (order != reference_order) {  // same primitives, SAH grouping, children ordered by distance to this camera
             rtk_optimize_opts oo{};
             oo.has_eye = 1;
@@ -193,7 +199,8 @@ public:
             rtk_optimize_info info{};
             rc = rtk_multi_scene_upload_fast(multi, &desc, &oo, &info);
             fast_order_exact = rc == RTK_OK && info.exact != 0;
-            used_fast_order = rc == RTK_OK && (order == fast_order || fast_order_exact);
+            fast_order_exactness = rc == RTK_OK ? info.exact : 0;
+            used_fast_order = rc == RTK_OK && (order == fast_order || info.exact == 2 || (info.exact == 1 && accept_empirical_order));
             // auto_order never makes render() fail on a scene the reference order accepts: fall back to it
             if (rc != RTK_OK && order == auto_order) rc = RTK_OK;
         }

@@ -217,9 +217,12 @@ private:
         n_comp = p[5];
         if (img_w <= 0 || img_h <= 0 || (n_comp != 1 && n_comp != 3) || len < 8 + 3 * n_comp) return false;
         // The planes below are sized from these 16-bit fields: believe them only if the file could hold such an image.
-        // Every 8x8 block costs at least two bits of entropy-coded data (a DC code and an end-of-block code), i.e. at
-        // most 256 pixels per byte of file; and nothing above 2^27 pixels is decoded at all.
-        if (uint64_t(img_w) * uint64_t(img_h) > (uint64_t(1) << 27) || uint64_t(img_w) * uint64_t(img_h) > uint64_t(end - src) * 256 + 4096) return false;
+        // A baseline scan costs every 8x8 block at least two bits of entropy-coded data (a DC code and an end-of-block
+        // code): at most 256 pixels per byte of file.  A PROGRESSIVE file gets by on one bit per block (its DC-first scan;
+        // the AC scans of a flat image collapse into end-of-band runs), i.e. up to 512 pixels per byte -- a uniform
+        // 1024x1024 progressive image is ~3 KB and the reference's stb_image loads it -- so the bound is 1024 pixels per byte
+        // whatever the frame type (slack of two over the progressive minimum).  Nothing above 2^27 pixels is decoded at all.
+        if (uint64_t(img_w) * uint64_t(img_h) > (uint64_t(1) << 27) || uint64_t(img_w) * uint64_t(img_h) > uint64_t(end - src) * 1024 + 4096) return false;
         h_max = v_max = 1;
         for (int c = 0; c < n_comp; c++) {
             comp[c].id = p[6 + 3 * c];

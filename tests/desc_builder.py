@@ -206,7 +206,7 @@ class BuiltDesc:
                           materials=arr(Material, b.materials), textures=arr(Texture, b.textures), tris=arr(Triangle, b.triangles), boxes=arr(Aabb, b.boxes))
         k = self._keep
         d = SceneDesc()
-        d.abi_version, d.root = 1, root
+        d.abi_version, d.root = 2, root  # RTK_ABI_VERSION
         d.n_nodes, d.n_list_children, d.n_spheres, d.n_quads = len(b.nodes), len(b.children), len(b.spheres), len(b.quads)
         d.n_triangles = len(b.triangles)
         d.n_bvh_boxes = len(b.boxes)

@@ -104,6 +104,24 @@ def make_jpeg_fixtures():
 
 
 
+def make_flat_progressive_jpeg():
+    """A uniform 1024x1024 progressive greyscale JPEG: ~1 bit per 8x8 block (the DC-first scan; the AC scans collapse into
+    end-of-band runs), i.e. more than 256 pixels per byte of file -- the file the loader's plausibility bound must not
+    reject (the reference's stb_image loads it).  The reference's texels are all one value: only that value is stored."""
+    from PIL import Image
+
+    path = os.path.join(HERE, "flat_prog_grey_1024x1024.jpg")
+    Image.fromarray(np.full((1024, 1024), 137, np.uint8), "L").save(path, "JPEG", optimize=True, progressive=True, quality=75)
+    prefix = os.path.join(tempfile.mkdtemp(), "flat")
+    subprocess.check_call([REF, "texels", path, prefix])
+    dims = np.fromfile(prefix + ".dims", np.int32)
+    assert dims.tolist() == [1024, 1024], dims
+    texels = np.fromfile(prefix + ".u8", np.uint8).reshape(1024, 1024, 3)
+    assert (texels == texels[0, 0]).all()
+    np.save(os.path.join(HERE, "flat_prog_grey_1024x1024_value.npy"), texels[0, 0].copy())
+    print("flat progressive:", os.path.getsize(path), "bytes,", 1024 * 1024 / os.path.getsize(path), "pixels per byte, value", texels[0, 0])
+
+
 def make_png_fixtures():
     """Small PNGs of every colour type / bit depth / interlace combination, hand-assembled (zlib + scanline filters of
     all five types) so that nothing depends on an imaging library's defaults, + the bytes the REFERENCE's rtw_image
@@ -214,5 +232,6 @@ if __name__ == "__main__":
         main()
     if "--png-only" not in sys.argv:
         make_jpeg_fixtures()
+        make_flat_progressive_jpeg()
     if "--jpeg-only" not in sys.argv:
         make_png_fixtures()

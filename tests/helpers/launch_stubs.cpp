@@ -21,6 +21,18 @@ hipError_t launch_debug_hit(const SceneView<real>&, int, const double*, const ui
 template hipError_t launch_debug_hit<double>(const SceneView<double>&, int, const double*, const uint32_t*, double*, unsigned long long*, hipStream_t);
 template hipError_t launch_debug_hit<float>(const SceneView<float>&, int, const double*, const uint32_t*, double*, unsigned long long*, hipStream_t);
 template <typename real>
+hipError_t launch_debug_scatter(const SceneView<real>&, int, const int32_t*, const double*, const double*, const uint32_t*, double*, unsigned long long*, hipStream_t) { return hipErrorNotSupported; }
+template hipError_t launch_debug_scatter<double>(const SceneView<double>&, int, const int32_t*, const double*, const double*, const uint32_t*, double*, unsigned long long*, hipStream_t);
+template hipError_t launch_debug_scatter<float>(const SceneView<float>&, int, const int32_t*, const double*, const double*, const uint32_t*, double*, unsigned long long*, hipStream_t);
+template <typename real>
+hipError_t launch_debug_texture(const SceneView<real>&, int, const int32_t*, const double*, double*, unsigned long long*, hipStream_t) { return hipErrorNotSupported; }
+template hipError_t launch_debug_texture<double>(const SceneView<double>&, int, const int32_t*, const double*, double*, unsigned long long*, hipStream_t);
+template hipError_t launch_debug_texture<float>(const SceneView<float>&, int, const int32_t*, const double*, double*, unsigned long long*, hipStream_t);
+template <typename real>
+hipError_t launch_debug_get_ray(const CameraRec<real>&, uint32_t, int, const int32_t*, double*, unsigned long long*, hipStream_t) { return hipErrorNotSupported; }
+template hipError_t launch_debug_get_ray<double>(const CameraRec<double>&, uint32_t, int, const int32_t*, double*, unsigned long long*, hipStream_t);
+template hipError_t launch_debug_get_ray<float>(const CameraRec<float>&, uint32_t, int, const int32_t*, double*, unsigned long long*, hipStream_t);
+template <typename real>
 hipError_t launch_unpermute(const void*, int, int, int, long long, void*, uint8_t*, hipStream_t) { return hipErrorNotSupported; }
 template hipError_t launch_unpermute<double>(const void*, int, int, int, long long, void*, uint8_t*, hipStream_t);
 template hipError_t launch_unpermute<float>(const void*, int, int, int, long long, void*, uint8_t*, hipStream_t);

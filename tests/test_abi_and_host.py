@@ -90,6 +90,31 @@ def test_multi_gpu_entry_points_fail_loudly_without_a_device(rt):
         assert err.value.code == -2 and "no CPU path" in str(err.value)
 
 
+def test_multi_enqueue_buffer_sets_and_waits_follow_the_two_frames_in_flight_rule(rt):
+    """rtk_render_multi_enqueue keeps two frames in flight: frame k renders into buffer set k % 2 while frame k - 1 is gathered
+    and un-permuted out of the other one, and from frame 2 on the renders first wait (on the device) for the release of their
+    set by frame k - 2.  rtk_multi_frame_plan IS the rule the enqueue follows (host-only); the ordering it implies is checked
+    here on a model of the streams: no buffer set is ever written while an earlier frame still reads it."""
+    lib = rt.hip_lib()
+    out = (C.c_int32 * 2)()
+    assert lib.rtk_multi_frame_plan(-1, out) == -1 and lib.rtk_multi_frame_plan(0, None) == -1
+    released_at = {}          # buffer set -> index of the frame whose un-permute released it last
+    for frame in range(9):
+        assert lib.rtk_multi_frame_plan(frame, out) == 0
+        slot, waits = out[0], out[1]
+        assert slot == frame % 2
+        # the set was last used by frame - 2: the renders of `frame` must wait for exactly that release, and only then
+        assert waits == (1 if frame >= 2 else 0)
+        if waits:
+            assert released_at[slot] == frame - 2
+        # frame - 1 lives in the OTHER set: its gather / un-permute overlap this frame's renders without a hazard
+        if frame >= 1:
+            assert released_at.get(1 - slot, frame - 1) == frame - 1
+        released_at[slot] = frame
+    # argument errors come before any device work; no device -> the usual loud failure, never a fallback
+    assert lib.rtk_render_multi_enqueue(None, None, None, None, None) == -1 and lib.rtk_multi_wait(None) == -1
+
+
 def test_package_never_touches_the_oracle():
     pkg = os.path.join(ROOT, "raytracingoneweekendapplication_amd")
     offenders = []

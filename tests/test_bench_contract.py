@@ -75,6 +75,65 @@ def test_roofline_arithmetic_and_stale_profile_refusal(tmp_path, monkeypatch):
     assert bench.load_pmc("c3", "k", "w 8x8x1", 1)[0] is None
 
 
+def test_work_based_fraction_arithmetic():
+    """roofline.work_frac = sum over units of work (exact counter x ISA-derived instruction cost, priced per class) / 64 lanes
+    / (1024 SIMDs x 2.4 GHz x kernel time): a number that depends on the work and the time only -- not on how many
+    instructions the kernel executed for it, nor on how full its waves were."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    zero = {"f32": 0, "f64": 0, "trans_f32": 0, "trans_f64": 0, "mul_i32": 0, "lds": 0, "vmem": 0, "salu": 0}
+    isa = {"costs": {k: dict(zero) for k in ("box", "sphere", "segment", "sample", "miss", "lambertian", "metal", "dielectric", "partial")}}
+    isa["costs"]["box"].update(f32=16)
+    isa["costs"]["sphere"].update(f32=10, f64=40, trans_f64=1)
+    isa["costs"]["lambertian"].update(f64=50)
+    isa["costs"]["metal"].update(f64=90)
+    isa["costs"]["dielectric"].update(f64=120)
+    counters = {"samples": 1000, "segments": 2600, "box_tests": 53000, "sphere_tests": 5400, "surface_hits": 1600}
+    cycles = {"f32": 2.0, "f64": 4.0, "trans_f32": 8.0, "trans_f64": 16.0, "mul_i32": 8.0}
+    r = bench.work_roofline(counters, isa, cycles, kernel_ms=1e-3)
+    lane_cycles = 53000 * 32.0 + 5400 * (20 + 160 + 16) + 1600 * 200.0      # the cheapest material prices a hit
+    want = lane_cycles / 64.0 / (1024 * 2.4e9 * 1e-6)
+    assert abs(r["work_frac"] - want) < 1e-4 * want + 1e-4
+    assert abs(sum(r["work_by_unit_share"].values()) - 1.0) < 1e-3
+    assert abs(bench.work_roofline(counters, isa, cycles, kernel_ms=2e-3)["work_frac"] - want / 2) < 1e-4   # twice the time, half the fraction
+    # measured issue rates replace the nominal prices class by class; missing ones fall back
+    got, src = bench.issue_cycles({"issue_v_fma_f32": 0.5, "issue_v_fma_f64": 0.25, "issue_v_mul_f64": 0.25, "issue_v_add_f64": 0.25, "issue_v_rcp_f64": 0.0625,
+                                   "issue_v_rcp_f32": 0.125, "issue_v_mul_lo_u32": 0.125})
+    assert got == {"f32": 2.0, "f64": 4.0, "trans_f32": 8.0, "trans_f64": 16.0, "mul_i32": 8.0} and "measured" in src
+    assert bench.issue_cycles(None)[0] == bench.NOMINAL_ISSUE_CYCLES
+    # the VALU-issue utilisation prices transcendentals at their own class when given the table
+    pmc = {"SQ_INSTS_VALU": 100.0, "SQ_INSTS_VALU_ADD_F64": 10.0, "SQ_INSTS_VALU_MUL_F64": 10.0, "SQ_INSTS_VALU_FMA_F64": 10.0, "SQ_INSTS_VALU_TRANS_F64": 5.0,
+           "SQ_INSTS_VALU_TRANS_F32": 5.0, "SQ_THREAD_CYCLES_VALU": 64.0, "SQ_ACTIVE_INST_VALU": 1.0}
+    u = bench.valu_roofline({"counters": pmc}, kernel_ms=1e-6, cycles=cycles)
+    assert abs(u["achieved"] - (30 * 4 + 5 * 16 + 5 * 8 + 60 * 2) / 1e-9 / 1e9) < 1e-3
+
+
+def test_isa_cost_table_is_derived_from_the_kernel_sources():
+    """tools/isa_costs.py: the per-unit instruction costs behind work_frac come from the ISA of probe kernels that run the
+    product's own step functions (compile-only: no GPU).  The table must be sane -- a box step is a couple of dozen f32-class
+    instructions and no f64 arithmetic, a sphere test is dominated by f64 -- and the committed table, when it was derived
+    from the present sources, must be exactly what the present sources give."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, ROOT)
+    import bench
+    import isa_costs
+
+    table = isa_costs.derive()
+    c = table["costs"]
+    assert set(c) == {"box", "sphere", "segment", "sample", "miss", "lambertian", "metal", "dielectric", "partial"}
+    assert 10 <= c["box"]["f32"] <= 30 and c["box"]["f64"] == 0 and c["box"]["trans_f64"] == 0
+    assert c["sphere"]["f64"] >= 30 and c["sphere"]["trans_f64"] >= 1          # discriminant, square root, the corrected quotients
+    assert c["lambertian"]["f64"] < c["metal"]["f64"] and c["lambertian"]["f64"] < c["dielectric"]["f64"]
+    assert isa_costs.pipe_cycles(c["box"]) < isa_costs.pipe_cycles(c["sphere"]) < isa_costs.pipe_cycles(c["sample"]) + isa_costs.pipe_cycles(c["lambertian"])
+    assert isa_costs.NOMINAL_CYCLES == bench.NOMINAL_ISSUE_CYCLES
+    path = os.path.join(ROOT, "profiles", f"{bench.PMC_ROUND}_isa_costs.json")
+    if os.path.exists(path):
+        committed = json.load(open(path))
+        if committed.get("source_hash") == bench.kernel_source_hash():
+            assert committed["costs"] == c
+
+
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_keys():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--width", "320", "--height", "200", "--spp", "24",
@@ -96,7 +155,36 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert key in r, key
     assert r["bound"] == "valu" and r["traffic"] is None and r["frac"] is None  # PMC profiles are quoted for the full-size workloads only
     assert "refused" in r["pmc"] and r["hbm_model"]["algorithmic_bytes_per_sample"] > 0 and r["hbm_model"]["box_record_bytes"] == 32
+    ceil = r["ceilings"]    # measured on this box in this run: a stream copy below the HBM spec, LDS far above it, f64 dearer than f32
+    assert 1000 < ceil["hbm_copy_GBps"] < 8000 and ceil["lds_read_b128_GBps"] > 10000 and ceil["lds_read_b128_random_records_GBps"] > 1000
+    ic = ceil["issue_cycles_per_wave_instruction"]
+    assert 1.5 < ic["f32"] < 3.0 and ic["f64"] > ic["f32"] and ic["trans_f64"] > ic["f64"] and "measured" in ceil["issue_cycles_source"]
+    assert 1.0 < ceil["shader_clock_GHz_under_valu_load"] <= 2.45
+    assert "work_frac" in r and (r["work_frac"] is None or 0 < r["work_frac"] < 1)
+    assert r["hbm_model"]["model_vs_lds_ceiling"] is not None
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     assert d["other_order"]["identical_framebuffer"] is True and d["other_order"]["fast_order_exact"] is True
     assert d["framebuffer_sha256"] == d["other_order"]["framebuffer_sha256"]
+
+
+@pytest.mark.gpu
+def test_bench_multi_abi_mode_reproduces_the_one_gpu_framebuffer():
+    """`bench.py --multi abi`: ONE process driving the product's own multi-GPU path (rtk_render_multi_enqueue / rtk_multi_wait,
+    two frames in flight) -- rehearsed on this one-GPU box with the device listed four times -- must print the same
+    framebuffer digest as the N = 1 line of the same workload, and the contract's keys."""
+    common = ["--steps", "3", "--warmup", "1", "--width", "320", "--height", "200", "--spp", "24"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common, "--no-cpu-baseline", "--no-f32", "--no-other-configs"],
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([line for line in one.stdout.splitlines() if line.startswith("{")][-1])
+    abi = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--multi", "abi", "--gpus", "4", "--multi-devices", "0,0,0,0", *common],
+                         capture_output=True, text=True, timeout=600)
+    assert abi.returncode == 0, abi.stderr[-2000:]
+    lines = [line for line in abi.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1
+    d4 = json.loads(lines[0])
+    assert d4["multi"] == "abi" and d4["n_gpus"] == 4 and d4["devices"] == [0, 0, 0, 0] and d4["uses_rccl"] is False
+    assert d4["framebuffer_sha256"] == d1["framebuffer_sha256"]
+    assert d4["value"] > 0 and d4["blocking_render_multi"]["value"] > 0
+    assert abs(d4["value"] - 320 * 200 * 24 / (d4["ms_per_step"] * 1e-3) / 1e6) / d4["value"] < 1e-3

@@ -78,14 +78,14 @@ def test_random_soups_render_identically_in_the_fast_order(rt, orc, seed):
 @pytest.mark.parametrize("seed", range(16))
 def test_random_soups_with_triangles_render_identically_in_the_fast_order(rt, orc, seed):
     """The same with triangles among the primitives (triangle.h:65-113: float determinant and barycentrics): bit-identical
-    again -- `exact` is claimed for triangle scenes too now that ties follow the reference's ranks."""
+    again in every case -- as a measurement: the pass reports triangle scenes as empirically exact (1), never proven (2)."""
     scene = random_scene(3000 + seed, triangles=True)
     cam = look_at_camera(rt)
     ref, ref8, rc = orc.render(scene.desc_ptr, cam, 7, 4)
     assert rc["triangle_tests"] > 0
     for eye in (cam.center, None):
         fast = rt.FastOrderScene(scene, eye)
-        assert fast.exact and fast.info["has_triangles"]
+        assert fast.exact and fast.info["has_triangles"] and not fast.proven
         got, got8, gc = orc.render(fast.desc_ptr, cam, 7, 4)
         assert np.array_equal(got, ref) and np.array_equal(got8, ref8), f"seed {seed}: max diff {np.abs(got - ref).max()}"
         for k in ("segments", "surface_hits", "rng_draws"):

@@ -27,6 +27,27 @@ def test_jpeg_texels_equal_the_reference_loaders_bytes(rt, name):
     assert np.array_equal(got, want)
 
 
+def test_flat_progressive_jpeg_above_256_pixels_per_byte_loads_like_the_reference(rt):
+    """A uniform 1024x1024 progressive greyscale JPEG costs a few bits per 8x8 block (libjpeg's default progression: 163 pixels
+    per byte of file; a DC-first scan without successive approximation gets to ~500, beyond what any baseline scan can reach).
+    The loader's plausibility bound (allocations are sized from header fields: 1024 pixels per byte + slack) must let such
+    files through -- the reference's stb_image loads them; the expected texels (one value everywhere) come from its loader."""
+    path = os.path.join(GOLDEN, "flat_prog_grey_1024x1024.jpg")
+    assert 1024 * 1024 / os.path.getsize(path) > 150
+    got = rt.load_image_texels(path)
+    want = np.load(os.path.join(GOLDEN, "flat_prog_grey_1024x1024_value.npy"), allow_pickle=False)
+    assert got is not None and got.shape == (1024, 1024, 3)
+    assert (got == want).all()
+    # ... while a header that claims far more pixels than the file could hold is still refused before anything is allocated
+    data = bytearray(open(path, "rb").read())
+    at = data.index(b"\xff\xc2") + 5     # SOF2: height, width as 16-bit big-endian fields
+    data[at:at + 4] = b"\xff\xff\xff\xff"
+    with tempfile.TemporaryDirectory() as tmp:
+        bad = os.path.join(tmp, "huge.jpg")
+        open(bad, "wb").write(bytes(data))
+        assert rt.load_image_texels(bad) is None
+
+
 PNG_FIXTURES = ["png_rgb8_13x7", "png_rgba8_9x9_adam7", "png_grey8_17x5", "png_grey4_11x6", "png_grey2_10x4_adam7", "png_grey1_19x3",
                 "png_greyalpha8_8x8", "png_grey16_6x5", "png_rgb16_7x4_adam7", "png_rgba16_5x5", "png_pal8_12x5", "png_pal4_9x7_adam7",
                 "png_pal2_15x2", "png_pal1_21x3", "png_rgb8_1x1_stored", "png_rgb8_64x48_fixedhuff"]

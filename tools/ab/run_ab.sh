@@ -12,6 +12,6 @@ done
 wait
 CFG=${AB_CONFIG:-c2}; SPP=${AB_SPP:-0}; REAL=${AB_REAL:-f64}
 for i in 1 2; do
-  for n in "$@"; do RTK_HIP_LIB=$PWD/gpurun_out/ab/$n.so python tools/render_once.py $CFG $REAL 3 $SPP | tail -1 | cut -c1-48 | sed "s/^/$n ($CFG): /"; done
+  for n in "$@"; do RTK_DEV_TOOLS=1 RTK_HIP_LIB=$PWD/gpurun_out/ab/$n.so python tools/render_once.py $CFG $REAL 3 $SPP | tail -1 | cut -c1-48 | sed "s/^/$n ($CFG): /"; done
   python tools/render_once.py $CFG $REAL 3 $SPP | tail -1 | cut -c1-48 | sed "s/^/current ($CFG): /"
 done

@@ -11,10 +11,13 @@ extra = os.environ.get("RTK_PROF_FLAGS", "").split()   # e.g. RTK_PROF_FLAGS="-D
 prof_lib = os.path.join(ROOT, "gpurun_out", "librtk_hip_prof%s.so" % ("_" + "_".join(f.strip("-D").replace("=", "") for f in extra) if extra else ""))
 os.makedirs(os.path.dirname(prof_lib), exist_ok=True)
 csrc = os.path.join(ROOT, "raytracingoneweekendapplication_amd", "csrc")
-if not os.path.exists(prof_lib) or os.path.getmtime(prof_lib) < os.path.getmtime(os.path.join(csrc, "rtk_trace.hip")):
+if os.environ.get("RTK_PROF_LIB"):   # a profile build made beforehand (tools/ab/build_local.sh name:"-DRTK_PROFILE"): nothing is compiled on the GPU box
+    prof_lib = os.environ["RTK_PROF_LIB"]
+elif not os.path.exists(prof_lib) or os.path.getmtime(prof_lib) < os.path.getmtime(os.path.join(csrc, "rtk_trace.hip")):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DRTK_PROFILE", *extra,
                            "-I" + os.path.join(ROOT, "include"), "-I" + csrc, os.path.join(csrc, "rtk_api.cpp"), os.path.join(csrc, "rtk_multi.cpp"), os.path.join(csrc, "rtk_optimize.cpp"), os.path.join(csrc, "rtk_trace.hip"), "-o", prof_lib])
 os.environ["RTK_HIP_LIB"] = prof_lib
+os.environ["RTK_DEV_TOOLS"] = "1"
 import torch
 import raytracingoneweekendapplication_amd as rt
 

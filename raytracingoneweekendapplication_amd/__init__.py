@@ -194,9 +194,16 @@ def hip_lib() -> C.CDLL:
         lib.rtk_render_host.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rtk_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.rtk_debug_closest_hit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        lib.rtk_debug_scatter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        lib.rtk_debug_texture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        lib.rtk_debug_get_ray.argtypes = [C.c_void_p, C.c_int, C.POINTER(Camera), C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        try:
+            lib.rtk_debug_scatter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            lib.rtk_debug_texture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            lib.rtk_debug_get_ray.argtypes = [C.c_void_p, C.c_int, C.POINTER(Camera), C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+            lib.rtk_render_multi_enqueue.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p, C.c_void_p]
+            lib.rtk_multi_wait.argtypes = [C.c_void_p]
+            lib.rtk_multi_frame_plan.argtypes = [C.c_int64, C.POINTER(C.c_int32)]
+        except AttributeError:
+            if HIP_LIB_PATH == DEFAULT_HIP_LIB_PATH:   # an A/B library of an older round (tools/, RTK_DEV_TOOLS=1) may lack the newer entry points
+                raise
         lib.rtk_scene_optimize.argtypes = [C.c_void_p, C.POINTER(OptimizeOpts), C.POINTER(C.c_void_p), C.POINTER(OptimizeInfo)]
         lib.rtk_scene_upload_fast.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OptimizeOpts), C.POINTER(OptimizeInfo)]
         lib.rtk_scene_optimized_free.restype = None
@@ -214,11 +221,8 @@ def hip_lib() -> C.CDLL:
         lib.rtk_multi_scene_upload_fast.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OptimizeOpts), C.POINTER(OptimizeInfo)]
         lib.rtk_render_multi_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p, C.c_void_p]
         lib.rtk_render_multi.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p, C.c_void_p]
-        lib.rtk_render_multi_enqueue.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.c_void_p, C.c_void_p]
-        lib.rtk_multi_wait.argtypes = [C.c_void_p]
-        lib.rtk_multi_frame_plan.argtypes = [C.c_int64, C.POINTER(C.c_int32)]
         lib.rtk_set_progress_callback.argtypes = [C.c_void_p, PROGRESS_FN, C.c_void_p, C.c_int]
-        if lib.rtk_abi_version() != RTK_ABI_VERSION:
+        if lib.rtk_abi_version() != RTK_ABI_VERSION and HIP_LIB_PATH == DEFAULT_HIP_LIB_PATH:
             raise RuntimeError("librtk_hip.so ABI version mismatch")
         _hip_lib = lib
     return _hip_lib

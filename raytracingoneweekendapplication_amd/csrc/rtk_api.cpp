@@ -947,12 +947,21 @@ struct rtk_ctx {
     rtk_progress_fn progress_fn = nullptr;
     void* progress_user = nullptr;
     int progress_interval_ms = 100;
-    const unsigned int* last_tile_counter = nullptr;
-    int64_t last_n_items = 0;
+    // a frame is up to kMaxPasses launches (one per range of sample chunks): the work-item counter of each and what it hands out
+    const unsigned int* last_tile_counter[4] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t last_pass_items[4] = {0, 0, 0, 0};
+    int last_n_passes = 0;
+    int64_t last_n_items = 0;               // of the whole frame
     hipStream_t progress_stream = nullptr;
-    unsigned int* progress_word = nullptr;  // pinned host memory
+    unsigned int* progress_word = nullptr;  // pinned host memory, one word per pass
     bool progress_pending = false;
 };
+// Sample chunks per launch: the partial-sum workspace holds this many planes [local tile][3][64] (+ one for the running sum
+// of a frame that needs several launches).  1920x1080: 16 planes of f64 = 0.8 GB, where the 63 chunks of a 1000-spp frame
+// used to take 3.1 GB per context (and 6.3 GB of write + read traffic per frame).
+constexpr int kMaxPlanesPerPass = 16;
+constexpr int kMaxPasses = (rtk::kMaxChunks + kMaxPlanesPerPass - 1) / kMaxPlanesPerPass;
+static_assert(kMaxPasses <= 4, "rtk_ctx keeps four pass counters");
 constexpr unsigned int kCounterRing = 256;
 constexpr size_t kCameraStride = 256;
 static_assert(sizeof(CameraRec<double>) <= kCameraStride, "camera stride");
@@ -984,7 +993,7 @@ int wait_with_progress(rtk_ctx* const* ctxs, const hipStream_t* streams, int n) 
         if (!c->progress_stream) {
             (void)hipSetDevice(c->device);
             if (hipStreamCreateWithFlags(&c->progress_stream, hipStreamNonBlocking) != hipSuccess) c->progress_stream = nullptr;
-            if (hipHostMalloc(reinterpret_cast<void**>(&c->progress_word), sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) c->progress_word = nullptr;
+            if (hipHostMalloc(reinterpret_cast<void**>(&c->progress_word), 4 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) c->progress_word = nullptr;
         }
         c->progress_pending = false;
     }
@@ -1003,15 +1012,25 @@ int wait_with_progress(rtk_ctx* const* ctxs, const hipStream_t* streams, int n) 
             int64_t done = 0;
             for (int i = 0; i < n; i++) {
                 rtk_ctx* c = ctxs[i];
-                if (c->progress_stream && c->progress_word && c->last_tile_counter) {
+                if (c->progress_stream && c->progress_word && c->last_n_passes > 0) {
                     (void)hipSetDevice(c->device);
                     if (c->progress_pending && hipStreamQuery(c->progress_stream) == hipSuccess) {
-                        seen[size_t(i)] = std::min<int64_t>(int64_t(*c->progress_word), c->last_n_items);
+                        int64_t sum = 0;  // a pass that has not started yet still shows the zero its counter was reset to at enqueue time ... or an older launch's count: clamp, and count a pass only once every earlier one is complete
+                        bool earlier_done = true;
+                        for (int p = 0; p < c->last_n_passes; p++) {
+                            const int64_t v = earlier_done ? std::min<int64_t>(int64_t(c->progress_word[p]), c->last_pass_items[p]) : 0;
+                            sum += v;
+                            earlier_done = earlier_done && v == c->last_pass_items[p];
+                        }
+                        seen[size_t(i)] = std::max(seen[size_t(i)], sum);
                         c->progress_pending = false;
                     }
-                    if (!c->progress_pending &&
-                        hipMemcpyAsync(c->progress_word, c->last_tile_counter, sizeof(unsigned int), hipMemcpyDeviceToHost, c->progress_stream) == hipSuccess)
-                        c->progress_pending = true;
+                    if (!c->progress_pending) {
+                        bool ok = true;
+                        for (int p = 0; p < c->last_n_passes && ok; p++)
+                            ok = hipMemcpyAsync(c->progress_word + p, c->last_tile_counter[p], sizeof(unsigned int), hipMemcpyDeviceToHost, c->progress_stream) == hipSuccess;
+                        c->progress_pending = ok;
+                    }
                 }
                 done += seen[size_t(i)];
             }
@@ -1259,7 +1278,13 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
         for (int k = n + 1; k <= kMaxChunks; k++) tm.chunk_start[k] = int16_t(spp);
     }
     const size_t elem = opts->real_mode == RTK_REAL_F64 ? sizeof(double) : sizeof(float);
-    const size_t need = size_t(tm.n_tiles_local) * tm.n_chunks * 192 * elem;
+    // Up to kMaxPlanesPerPass chunks per launch; a frame with more is rendered in consecutive passes, the resolve kernel
+    // carrying the running sum in one extra plane -- the same additions in the same order as one pass over all chunks.
+    const int n_chunks_total = tm.n_chunks;
+    const int planes_per_pass = (opts->variant & (1 << 24)) ? kMaxChunks : kMaxPlanesPerPass;  // variant bit 24: one pass whatever the chunk count (tests: same image)
+    const int n_passes = (n_chunks_total + planes_per_pass - 1) / planes_per_pass;
+    const size_t plane = size_t(tm.n_tiles_local) * 192 * elem;
+    const size_t need = plane * size_t(n_passes > 1 ? planes_per_pass + 1 : n_chunks_total);
     if (need > ctx->partial_bytes) {
         if (ctx->d_partial) {
             RTK_HIP(hipDeviceSynchronize());  // earlier launches may still read the old workspace
@@ -1292,10 +1317,8 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
     if (!ctx->order_valid && learn) RTK_HIP(hipMemsetAsync(ctx->d_tile_cost, 0, size_t(tm.n_tiles_local) * sizeof(unsigned int), stream));
     const int32_t* tile_order = (ctx->order_valid && learn) ? ctx->d_tile_order : nullptr;
     unsigned int* tile_cost = learn ? ctx->d_tile_cost : nullptr;
-    const unsigned int slot = ctx->next_counter++ % kCounterRing;
-    unsigned int* tile_counter = ctx->tile_counters + slot;
-    ctx->last_tile_counter = tile_counter;
-    ctx->last_n_items = int64_t(tm.n_tiles_local) * tm.n_chunks;
+    ctx->last_n_passes = n_passes;
+    ctx->last_n_items = int64_t(tm.n_tiles_local) * n_chunks_total;
     const int cam_mode = opts->real_mode == RTK_REAL_F64 ? 0 : 1;
     const bool cam_cached = ctx->cam_valid[cam_mode] && std::memcmp(&ctx->cam_last[cam_mode], cam, sizeof(rtk_camera)) == 0;
     const unsigned int cslot = cam_cached ? ctx->cam_slot[cam_mode] : (ctx->next_camera++ % kCounterRing);
@@ -1310,23 +1333,43 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
     unsigned char* d_cam = ctx->d_cameras + cslot * kCameraStride;
     const bool allow_lds = (opts->variant & 1) == 0;  // variant bit 0: keep the program in global memory (A/B)
     const uint32_t diag = uint32_t(opts->variant) & 0xBFFF00u;  // bits 8..21, 23: scheduler policy / program layout A/B used by tools/ and tests only
-    hipError_t e;
-    if (opts->real_mode == RTK_REAL_F64) {
-        if (!cam_cached) {
+    hipError_t e = hipSuccess;
+    if (!cam_cached) {
+        if (opts->real_mode == RTK_REAL_F64) {
             ctx->h_cameras64[cslot] = to_device_camera<double>(*cam);
             RTK_HIP(hipMemcpyAsync(d_cam, &ctx->h_cameras64[cslot], sizeof(CameraRec<double>), hipMemcpyHostToDevice, stream));
-        }
-        e = launch_render<double>(ctx->scene64.view, reinterpret_cast<const CameraRec<double>*>(d_cam), tm, opts->seed, ctx->features,
-                                  opts->count_work != 0, allow_lds, diag, ctx->d_partial, counters, tile_counter, tile_order, tile_cost, stream);
-        if (e == hipSuccess) e = launch_resolve<double>(ctx->d_partial, tm, cam->image_width, cam->image_height, cam->pixel_samples_scale, d_linear, d_rgb8, stream);
-    } else {
-        if (!cam_cached) {
+        } else {
             ctx->h_cameras32[cslot] = to_device_camera<float>(*cam);
             RTK_HIP(hipMemcpyAsync(d_cam, &ctx->h_cameras32[cslot], sizeof(CameraRec<float>), hipMemcpyHostToDevice, stream));
         }
-        e = launch_render<float>(ctx->scene32.view, reinterpret_cast<const CameraRec<float>*>(d_cam), tm, opts->seed, ctx->features,
-                                 opts->count_work != 0, allow_lds, diag, ctx->d_partial, counters, tile_counter, tile_order, tile_cost, stream);
-        if (e == hipSuccess) e = launch_resolve<float>(ctx->d_partial, tm, cam->image_width, cam->image_height, cam->pixel_samples_scale, d_linear, d_rgb8, stream);
+    }
+    void* const acc = n_passes > 1 ? static_cast<char*>(ctx->d_partial) + plane * size_t(planes_per_pass) : nullptr;
+    unsigned int* pass_counter[kMaxPasses];
+    for (int pass = 0; pass < n_passes; pass++) {  // every pass's work-item counter reads 0 from now on (progress reports add them up)
+        pass_counter[pass] = ctx->tile_counters + (ctx->next_counter++ % kCounterRing);
+        if (n_passes > 1) RTK_HIP(hipMemsetAsync(pass_counter[pass], 0, sizeof(unsigned int), stream));
+    }
+    for (int pass = 0; pass < n_passes && e == hipSuccess; pass++) {
+        const int c0 = pass * planes_per_pass, c1 = std::min(n_chunks_total, c0 + planes_per_pass);
+        TileMap tp = tm;  // this pass's chunks, numbered from 0: planes, work items and chunk boundaries are the pass's own
+        tp.n_chunks = c1 - c0;
+        for (int k = 0; k <= kMaxChunks; k++) tp.chunk_start[k] = tm.chunk_start[std::min(c0 + k, n_chunks_total)];
+        unsigned int* tile_counter = pass_counter[pass];
+        ctx->last_tile_counter[pass] = tile_counter;
+        ctx->last_pass_items[pass] = int64_t(tp.n_tiles_local) * tp.n_chunks;
+        unsigned int* pass_cost = pass == 0 ? tile_cost : nullptr;  // a tile's cost is measured on every pixel's first chunk
+        const bool first = pass == 0, last = pass + 1 == n_passes;
+        if (opts->real_mode == RTK_REAL_F64) {
+            e = launch_render<double>(ctx->scene64.view, reinterpret_cast<const CameraRec<double>*>(d_cam), tp, opts->seed, ctx->features,
+                                      opts->count_work != 0, allow_lds, diag, ctx->d_partial, counters, tile_counter, tile_order, pass_cost, stream);
+            if (e == hipSuccess)
+                e = launch_resolve<double>(ctx->d_partial, tp, cam->image_width, cam->image_height, cam->pixel_samples_scale, d_linear, d_rgb8, acc, first, last, stream);
+        } else {
+            e = launch_render<float>(ctx->scene32.view, reinterpret_cast<const CameraRec<float>*>(d_cam), tp, opts->seed, ctx->features,
+                                     opts->count_work != 0, allow_lds, diag, ctx->d_partial, counters, tile_counter, tile_order, pass_cost, stream);
+            if (e == hipSuccess)
+                e = launch_resolve<float>(ctx->d_partial, tp, cam->image_width, cam->image_height, cam->pixel_samples_scale, d_linear, d_rgb8, acc, first, last, stream);
+        }
     }
     if (e == hipSuccess && learn) {  // this frame's costs become the next frame's hand-out order
         e = launch_tile_order(ctx->d_tile_cost, tm.n_tiles_local, ctx->d_tile_order, stream);

@@ -12,7 +12,8 @@
 //   lds_roundtrip_cycles   dependent ds_read_b32 chain: shader cycles per round trip, one wave per SIMD
 //   issue_<class>          wave64 instructions issued per shader cycle per SIMD, 8 independent chains per lane and
 //                          8 waves per SIMD, for v_fma_f32, v_fma_f64, v_mul_f64, v_add_f64, v_mul_lo_u32, v_rcp_f32,
-//                          v_sqrt_f32, v_rcp_f64, v_rsq_f64, v_sqrt_f64 (the TRANS classes), v_cndmask_b32, v_max3_f32
+//                          v_sqrt_f32, v_rcp_f64, v_rsq_f64, v_sqrt_f64 (the TRANS classes), v_cndmask_b32, v_max3_f32,
+//                          v_pk_fma_f32 / v_pk_mul_f32 (two f32 operations per lane and instruction)
 //   shader_clock_GHz       s_memtime ticks per wall-clock second while the issue kernels run
 //
 // C ABI: rtk_microbench_run(device, out, n) fills out[0..n) in the order of rtk_microbench_names() (comma separated).
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(64) void lds_chain_kernel(int iters, unsigned long 
     if (at == 0xFFFFFFFFu) *sink = at;
 }
 
-enum IssueClass { I_FMA_F32, I_FMA_F64, I_MUL_F64, I_ADD_F64, I_MUL_LO_U32, I_RCP_F32, I_SQRT_F32, I_RCP_F64, I_RSQ_F64, I_SQRT_F64, I_CNDMASK, I_MAX3_F32, I_COUNT };
+enum IssueClass { I_FMA_F32, I_FMA_F64, I_MUL_F64, I_ADD_F64, I_MUL_LO_U32, I_RCP_F32, I_SQRT_F32, I_RCP_F64, I_RSQ_F64, I_SQRT_F64, I_CNDMASK, I_MAX3_F32, I_PK_FMA_F32, I_PK_MUL_F32, I_DS_READ_B128_FMA, I_COUNT };
 
 // 8 independent chains per lane x 16 instructions per trip
 template <int CLS>
@@ -111,6 +112,8 @@ __global__ __launch_bounds__(512) void issue_kernel(int iters, unsigned long lon
                 if (CLS == I_SQRT_F64) asm volatile("v_sqrt_f64 %0, %0" : "+v"(d[k]));
                 if (CLS == I_CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(f[k]) : "v"(fb));
                 if (CLS == I_MAX3_F32) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(f[k]) : "v"(fb), "v"(fc));
+                if (CLS == I_PK_FMA_F32) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(d[k]) : "v"(db), "v"(dc));   // (two f32 lanes in a 64-bit pair)
+                if (CLS == I_PK_MUL_F32) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(d[k]) : "v"(db));
             }
         }
     }
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(512) void issue_kernel(int iters, unsigned long lon
 const char* kNames =
     "hbm_copy_GBps,hbm_read_GBps,lds_read_b128_GBps,lds_read_b128_random_GBps,lds_roundtrip_cycles,shader_clock_GHz,"
     "issue_v_fma_f32,issue_v_fma_f64,issue_v_mul_f64,issue_v_add_f64,issue_v_mul_lo_u32,issue_v_rcp_f32,issue_v_sqrt_f32,issue_v_rcp_f64,issue_v_rsq_f64,"
-    "issue_v_sqrt_f64,issue_v_cndmask_b32,issue_v_max3_f32";
+    "issue_v_sqrt_f64,issue_v_cndmask_b32,issue_v_max3_f32,issue_v_pk_fma_f32,issue_v_pk_mul_f32,issue_unused";
 constexpr int kResults = 6 + I_COUNT;
 
 #define MB_HIP(call)                                  \
@@ -247,6 +250,8 @@ int rtk_microbench_run(int device, double* out, int n_out) {
     if (rc == 0) rc = run_issue<I_SQRT_F64>(cus, d_cycles, d_fsink, &out[6 + I_SQRT_F64], nullptr);
     if (rc == 0) rc = run_issue<I_CNDMASK>(cus, d_cycles, d_fsink, &out[6 + I_CNDMASK], nullptr);
     if (rc == 0) rc = run_issue<I_MAX3_F32>(cus, d_cycles, d_fsink, &out[6 + I_MAX3_F32], nullptr);
+    if (rc == 0) rc = run_issue<I_PK_FMA_F32>(cus, d_cycles, d_fsink, &out[6 + I_PK_FMA_F32], nullptr);
+    if (rc == 0) rc = run_issue<I_PK_MUL_F32>(cus, d_cycles, d_fsink, &out[6 + I_PK_MUL_F32], nullptr);
     (void)hipFree(src);
     (void)hipFree(dst);
     (void)hipFree(sink);

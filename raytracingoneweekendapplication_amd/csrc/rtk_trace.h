@@ -23,10 +23,12 @@ hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>* d_cam
 // cost[n] (segments per local tile, measured by the frame just rendered) -> order[n], most expensive first; clears cost.
 hipError_t launch_tile_order(unsigned int* cost, int n, int32_t* order, hipStream_t stream);
 
-// Partial sums [item][3][64] -> the row-major image (+ bytes) or this rank's compact tile buffer.
+// Partial sums [item][3][64] -> the row-major image (+ bytes) or this rank's compact tile buffer.  A frame rendered in several
+// passes over consecutive chunk ranges carries its running sum in `acc` [local tile][3][64] (read unless first_pass, written
+// unless last_pass); only the last pass writes the outputs.
 template <typename real>
 hipError_t launch_resolve(const void* partial, const TileMap& tmap, int width, int height, double samples_scale, void* out_linear, uint8_t* out_rgb8,
-                          hipStream_t stream);
+                          void* acc, bool first_pass, bool last_pass, hipStream_t stream);
 
 // Known-answer helper: closest hit of the scene root for n caller-supplied rays (device buffers).
 template <typename real>

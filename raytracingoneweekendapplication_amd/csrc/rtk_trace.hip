@@ -93,6 +93,20 @@ template <typename real> RTK_DEV bool near_zero(V3<real> a) {
     const real s = real(1e-8);
     return rt_fabs(a.x) < s && rt_fabs(a.y) < s && rt_fabs(a.z) < s;
 }
+// x^5 for Schlick's approximation (material.h:73: pow((1 - cosine), 5)).  double: the correctly rounded value, from products
+// carried as (value, rounding error) pairs -- x^2 = x2 + e2 exactly (one fused multiply-add recovers the error), x^4 = x4 + e4,
+// x^5 = x5 + e5 to ~2^-100, so the final sum rounds like the exact power (0 mismatches against exact rational arithmetic in
+// 2e5 arguments, tests/test_schlick_power.py).  float (statistical parity only): three plain products.
+RTK_DEV double pow5(double x) {
+    const double x2 = x * x, e2 = __builtin_fma(x, x, -x2);
+    const double x4 = x2 * x2, e4 = __builtin_fma(x2, x2, -x4) + 2.0 * (x2 * e2);
+    const double x5 = x4 * x, e5 = __builtin_fma(x4, x, -x5) + e4 * x;
+    return x5 + e5;
+}
+RTK_DEV float pow5(float x) {
+    const float x2 = x * x;
+    return x2 * x2 * x;
+}
 template <typename real> RTK_DEV V3<real> reflect(V3<real> v, V3<real> n) { return v - scale(real(2) * dot(v, n), n); }  // vec3.h:125-127
 template <typename real> RTK_DEV V3<real> refract(V3<real> uv, V3<real> n, real eta) {                                  // vec3.h:128-133
     real cos_theta = rt_fmin(dot(-uv, n), real(1));
@@ -441,6 +455,7 @@ struct Lane {
 #endif
     float tmin32, tmax32;
     V3<float> inv32s, oi32s; // lean MIXED kernel (RTK_CH_SCALED): inv32 and oi32 times 1 / (end of the current interval), see rescale32
+    V3<float> ainv32s;       // RTK_PK_BOX: |inv32s| (a packed instruction has no |.| source modifier)
     float m2slack32;         // COMPACT kernels with centre / half-extent boxes: -2 x the ray's slack (slab_test32_che)
     real a, inv_a, tm;       // d.d (sphere.h:35, hoisted likewise) and 1/(d.d) for divide_by; ray time
     real tmin, best_t;       // current query interval: (tmin, closest so far)
@@ -578,6 +593,9 @@ RTK_DEV void rescale32(Lane<real>& L, float extent) {
     const float s = __builtin_amdgcn_rcpf(end) * 0.99999976f;
     L.inv32s = V3<float>{L.inv32.x * s, L.inv32.y * s, L.inv32.z * s};
     L.oi32s = V3<float>{L.oi32.x * s, L.oi32.y * s, L.oi32.z * s};
+#if RTK_PK_BOX
+    L.ainv32s = V3<float>{__builtin_fabsf(L.inv32s.x), __builtin_fabsf(L.inv32s.y), __builtin_fabsf(L.inv32s.z)};
+#endif
 }
 // A primitive test accepted t: it is the closest hit so far (hittable_list.h:27-31 / bvh.h:69 shrink the interval).
 template <bool MIXED, bool SCALED = false, typename real>
@@ -716,6 +734,21 @@ RTK_DEV void step_box32_che(Lane<real>& L, const MixedHead& rec, Counters<COUNT>
 // clamped to the same end -- the box lies wholly before 0 or wholly beyond 1.
 RTK_DEV float max3_clamp01(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 RTK_DEV float min3_clamp01(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// ... with packed f32 arithmetic (RTK_PK_BOX, A/B): v_pk_fma_f32 computes two fused multiply-adds per lane and instruction --
+// the centre terms of x and y in one, then per axis the pair (near, far) = (tc - h |inv|, tc + h |inv|) in one: five
+// instructions instead of nine.  |inv| cannot be a source modifier of a packed instruction: the lane keeps it (ainv32s).
+#ifndef RTK_PK_BOX
+#define RTK_PK_BOX 0
+#endif
+typedef float pk2f __attribute__((ext_vector_type(2)));
+RTK_DEV bool slab_test32_chs_pk(const MixedHead& b, V3<float> oi, V3<float> inv, V3<float> ainv) {
+    const pk2f tcxy = __builtin_elementwise_fma(pk2f{b.f(0), b.f(1)}, pk2f{inv.x, inv.y}, pk2f{-oi.x, -oi.y});
+    const float tcz = __builtin_fmaf(b.f(2), inv.z, -oi.z);
+    const pk2f nfx = __builtin_elementwise_fma(pk2f{-b.f(3), b.f(3)}, pk2f{ainv.x, ainv.x}, pk2f{tcxy.x, tcxy.x});
+    const pk2f nfy = __builtin_elementwise_fma(pk2f{-b.f(4), b.f(4)}, pk2f{ainv.y, ainv.y}, pk2f{tcxy.y, tcxy.y});
+    const pk2f nfz = __builtin_elementwise_fma(pk2f{-b.f(5), b.f(5)}, pk2f{ainv.z, ainv.z}, pk2f{tcz, tcz});
+    return min3_clamp01(nfx.y, nfy.y, nfz.y) > max3_clamp01(nfx.x, nfy.x, nfz.x);
+}
 RTK_DEV bool slab_test32_chs(const MixedHead& b, V3<float> oi, V3<float> inv) {
     const float tcx = __builtin_fmaf(b.f(0), inv.x, -oi.x), tcy = __builtin_fmaf(b.f(1), inv.y, -oi.y), tcz = __builtin_fmaf(b.f(2), inv.z, -oi.z);
     const float ax = __builtin_fabsf(inv.x), ay = __builtin_fabsf(inv.y), az = __builtin_fabsf(inv.z);
@@ -727,7 +760,9 @@ RTK_DEV bool slab_test32_chs(const MixedHead& b, V3<float> oi, V3<float> inv) {
 template <typename real, bool COUNT>
 RTK_DEV void step_box32_ch(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cnt) {
     cnt.inc(C_BOX);
-#if RTK_CH_SCALED
+#if RTK_CH_SCALED && RTK_PK_BOX
+    const bool hit = slab_test32_chs_pk(rec, L.oi32s, L.inv32s, L.ainv32s);
+#elif RTK_CH_SCALED
     const bool hit = slab_test32_chs(rec, L.oi32s, L.inv32s);
 #else
     const bool hit = slab_test32_ch(rec, L.oi32, L.inv32, L.tmin32, L.tmax32);
@@ -1219,14 +1254,14 @@ RTK_DEV bool shade_surface(Lane<real>& L, const Surface<real>& sf, const SceneVi
         bool reflect_it = ri * sin_theta > real(1);
         if (!reflect_it) {  // Schlick (material.h:69-74); the draw is skipped on total internal reflection
             const real r0 = sf.front_face ? m.albedo[1] : m.albedo[2];
-            // Schlick's (1 - cos)^5 (material.h:73 calls pow) as ((x^2)^2)*x: within 2 ulp of the correctly rounded
-            // power instead of pow's 1, for ~200 instructions less in the dielectric branch.  The value only feeds the
-            // comparison with a 24-bit uniform below, so a different outcome needs the reflectance to lie within 2 ulp
-            // of a multiple of 2^-24 (probability ~1e-8 per dielectric interaction; the oracle comparison of every test
-            // scene is unchanged).
+            // Schlick's (1 - cos)^5 (material.h:73 calls pow) by multiplication, ~200 instructions less than pow in the
+            // dielectric branch -- in f64 CORRECTLY ROUNDED (pow5: the products carried with their rounding errors), which is
+            // what glibc's pow returns in 99.92 % of cases (tests/test_schlick_power.py; the plain ((x^2)^2)*x of rounds 1-2
+            // agreed with it in 49 %).  The value only feeds the comparison with a 24-bit uniform below: a different outcome
+            // needs pow's own misrounding AND the reflectance within an ulp of a multiple of 2^-24 -- ~1e-12 per dielectric
+            // interaction, i.e. ~1e-4 per full C2 frame (it was ~1e-9 and 0.1-1 per frame).
             const real omc = real(1) - cos_theta;
-            const real omc2 = omc * omc;
-            const real refl = r0 + (real(1) - r0) * (omc2 * omc2 * omc);
+            const real refl = r0 + (real(1) - r0) * pow5(omc);
             reflect_it = refl > rnd<real>(L.rng, cnt);
         }
         next_d = reflect_it ? reflect(unit_d, sf.normal) : refract(unit_d, sf.normal, ri);
@@ -2125,27 +2160,16 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
 #endif
             RTK_PROF_MARK(7, 1, popcount64(__ballot(alive)))
         } else {
-            // Rare records come in short runs too -- book 2's two media are neighbours in the program, an instance is entered
-            // and left through two chain switches around a small subtree: stay (up to RTK_OTHER_LOOP steps) while at least half
-            // of the starters still sit on a rare record, instead of paying a vote for each.
-#ifndef RTK_OTHER_LOOP
-#define RTK_OTHER_LOOP 4
-#endif
-            bool mine = (m_oth >> lane & 1ull) != 0ull;
-            [[maybe_unused]] const int keep_oth = (n_oth + 1) >> 1;
-            [[maybe_unused]] int rounds = 0, n_mine = 0;
-            do {
-                if (mine) {
-                    if constexpr (MIXED && !COMPACT) step_other_mixed<kPcUnit>(L, rec_at(L.pc), cnt, tie, extent);
-                    else step_other<real, FEAT, COUNT>(L, prog + L.pc, sc, cnt, tie, extent);
-                    const uint32_t k2 = kind_of(L.pc);
-                    L.kind = k2;
-                    mine = k2 != L.box_kind && k2 != OP_SPHERE && k2 != OP_END && !((FEAT & F_QUAD) && k2 == OP_QUAD) && !((FEAT & F_TRI) && k2 == OP_TRI);
-                }
-                RTK_PROF_MARK(4, 1, n_oth)
-                if constexpr (RTK_OTHER_LOOP <= 1 || (MIXED && !COMPACT)) break;
-                n_mine = popcount64(__ballot(mine));
-            } while (n_mine >= keep_oth && ++rounds < RTK_OTHER_LOOP);
+            // (A short loop here -- stay while at least half of the starters still sit on a rare record: book 2's two media are
+            // neighbours in the program, an instance is entered and left through two chain switches -- was measured and
+            // removed in round 3: C5 42.55 vs 42.10 ms at 32 spp, C4 15.47 vs 15.38, and the quad/box kernel lost 27 % to it,
+            // C3 33.6 vs 26.3 ms at 100 spp.)
+            if (m_oth >> lane & 1ull) {
+                if constexpr (MIXED && !COMPACT) step_other_mixed<kPcUnit>(L, rec_at(L.pc), cnt, tie, extent);
+                else step_other<real, FEAT, COUNT>(L, prog + L.pc, sc, cnt, tie, extent);
+                L.kind = kind_of(L.pc);
+            }
+            RTK_PROF_MARK(4, 1, n_oth)
         }
     }
     RTK_PROF_FLUSH
@@ -2334,9 +2358,13 @@ hipError_t launch_tile_order(unsigned int* cost, int n, int32_t* order, hipStrea
 // order, scale by 1/spp (Camera.txt:74) and write either the row-major image
 // (+ gamma/clamp/quantised bytes, Camera.txt:77-89) or this rank's compact tile
 // buffer.  One thread per (local tile, pixel).
+// A frame with more sample chunks than the workspace has planes (kMaxPlanesPerPass) is rendered in several passes over
+// consecutive chunk ranges; `acc` [local tile][3][64] carries the running sum from pass to pass.  The additions happen in the
+// same order as in one pass over all chunks -- c0, + c1, + c2, ... -- so the image does not depend on the number of passes.
 template <typename real>
 __global__ __launch_bounds__(256) void rtk_resolve_kernel(const real* __restrict__ partial, TileMap tmap, int width, int height, real samples_scale,
-                                                           real* __restrict__ out_linear, uint8_t* __restrict__ out_rgb8) {
+                                                           real* __restrict__ out_linear, uint8_t* __restrict__ out_rgb8, real* __restrict__ acc, int first_pass,
+                                                           int last_pass) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     const int pix = int(gid & 63);
     const long long local_tile = gid >> 6;
@@ -2348,13 +2376,27 @@ __global__ __launch_bounds__(256) void rtk_resolve_kernel(const real* __restrict
     if (inside) {
         const real* src = partial + size_t(local_tile) * 192 + pix;
         const size_t chunk_stride = size_t(tmap.n_tiles_local) * 192;
-        sum = mk(src[0], src[64], src[128]);
-        for (int c = 1; c < tmap.n_chunks; c++) {
+        int c = 0;
+        if (first_pass) {
+            sum = mk(src[0], src[64], src[128]);
+            c = 1;
+        } else {
+            const real* a = acc + size_t(local_tile) * 192 + pix;
+            sum = mk(a[0], a[64], a[128]);
+        }
+        for (; c < tmap.n_chunks; c++) {
             const real* q = src + size_t(c) * chunk_stride;
             sum = sum + mk(q[0], q[64], q[128]);
         }
+        if (!last_pass) {
+            real* a = acc + size_t(local_tile) * 192 + pix;
+            a[0] = sum.x;
+            a[64] = sum.y;
+            a[128] = sum.z;
+        }
         sum = scale(samples_scale, sum);
     }
+    if (!last_pass) return;
     if (tmap.compact) {
         if (out_linear) {
             real* base = out_linear + size_t(local_tile) * 192 + pix;
@@ -2672,15 +2714,16 @@ template const char* render_kernel_name<float>(const SceneView<float>&, uint32_t
 
 template <typename real>
 hipError_t launch_resolve(const void* partial, const TileMap& tmap, int width, int height, double samples_scale, void* out_linear, uint8_t* out_rgb8,
-                          hipStream_t stream) {
+                          void* acc, bool first_pass, bool last_pass, hipStream_t stream) {
     const long long slots = (long long)tmap.n_tiles_local * 64;
     if (slots <= 0) return hipSuccess;
     rtk_resolve_kernel<real><<<dim3(int((slots + 255) / 256)), dim3(256), 0, stream>>>(static_cast<const real*>(partial), tmap, width, height,
-                                                                                      real(samples_scale), static_cast<real*>(out_linear), out_rgb8);
+                                                                                      real(samples_scale), static_cast<real*>(out_linear), out_rgb8,
+                                                                                      static_cast<real*>(acc), first_pass ? 1 : 0, last_pass ? 1 : 0);
     return hipGetLastError();
 }
-template hipError_t launch_resolve<double>(const void*, const TileMap&, int, int, double, void*, uint8_t*, hipStream_t);
-template hipError_t launch_resolve<float>(const void*, const TileMap&, int, int, double, void*, uint8_t*, hipStream_t);
+template hipError_t launch_resolve<double>(const void*, const TileMap&, int, int, double, void*, uint8_t*, void*, bool, bool, hipStream_t);
+template hipError_t launch_resolve<float>(const void*, const TileMap&, int, int, double, void*, uint8_t*, void*, bool, bool, hipStream_t);
 
 template <typename real>
 hipError_t launch_debug_hit(const SceneView<real>& sc, int n, const double* d_rays, const uint32_t* d_keys, double* d_out, unsigned long long* d_draws,

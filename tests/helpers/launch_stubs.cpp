@@ -13,9 +13,9 @@ template hipError_t launch_render<float>(const SceneView<float>&, const CameraRe
                                          unsigned long long*, unsigned int*, const int32_t*, unsigned int*, hipStream_t);
 hipError_t launch_tile_order(unsigned int*, int, int32_t*, hipStream_t) { return hipErrorNotSupported; }
 template <typename real>
-hipError_t launch_resolve(const void*, const TileMap&, int, int, double, void*, uint8_t*, hipStream_t) { return hipErrorNotSupported; }
-template hipError_t launch_resolve<double>(const void*, const TileMap&, int, int, double, void*, uint8_t*, hipStream_t);
-template hipError_t launch_resolve<float>(const void*, const TileMap&, int, int, double, void*, uint8_t*, hipStream_t);
+hipError_t launch_resolve(const void*, const TileMap&, int, int, double, void*, uint8_t*, void*, bool, bool, hipStream_t) { return hipErrorNotSupported; }
+template hipError_t launch_resolve<double>(const void*, const TileMap&, int, int, double, void*, uint8_t*, void*, bool, bool, hipStream_t);
+template hipError_t launch_resolve<float>(const void*, const TileMap&, int, int, double, void*, uint8_t*, void*, bool, bool, hipStream_t);
 template <typename real>
 hipError_t launch_debug_hit(const SceneView<real>&, int, const double*, const uint32_t*, double*, unsigned long long*, hipStream_t) { return hipErrorNotSupported; }
 template hipError_t launch_debug_hit<double>(const SceneView<double>&, int, const double*, const uint32_t*, double*, unsigned long long*, hipStream_t);

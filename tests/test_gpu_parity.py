@@ -330,6 +330,40 @@ def test_config4_and_config5_full_resolution_reduced_spp_properties(rt, orc, ren
     assert np.array_equal(fast, img)
 
 
+def test_frames_with_many_sample_chunks_are_rendered_in_passes_with_the_same_sums(rt, orc, renderer, scenes):
+    """More than 16 sample chunks (spp > 128): the frame is rendered in passes of 16 chunks, the resolve kernel carrying every
+    pixel's running sum from pass to pass, so that the partial-sum workspace stays at 17 planes (1000 spp used to take 63).
+    The additions are those of one pass over all chunks, in the same order: the image must be the one-launch image (variant
+    bit 24) bit for bit -- whole, sharded over ranks, in float -- and the oracle's within rounding; progress reports of a
+    blocking render add the passes up monotonically."""
+    scene = scenes("book1_final")
+    cam = scene.camera(96, 54, 8 * 37, 12)           # 37 chunks of 8 samples: passes of 16 + 16 + 5
+    renderer.upload_fast(scene, cam.center)
+    seen = []
+    renderer.set_progress(lambda done, total: seen.append((done, total)), interval_ms=1)
+    passes, passes8, _ = renderer.render_host(cam)
+    renderer.set_progress(None)
+    one, one8, _ = renderer.render_host(cam, variant=1 << 24)
+    assert np.array_equal(passes, one) and np.array_equal(passes8, one8)
+    n_items = -(-96 // 8) * -(-54 // 8) * 37
+    assert seen and seen[-1] == (n_items, n_items) and all(0 <= a[0] <= b[0] <= b[1] for a, b in zip(seen, seen[1:]))
+    ref, ref8, _ = orc.render(scene.desc_ptr, cam, RENDER_SEED, 8)
+    assert np.sqrt(np.mean((passes - ref) ** 2)) < 1e-12 and np.array_equal(passes8, ref8)
+    f32_passes, _, _ = renderer.render_host(cam, real_mode=rt.RTK_REAL_F32)
+    f32_one, _, _ = renderer.render_host(cam, real_mode=rt.RTK_REAL_F32, variant=1 << 24)
+    assert np.array_equal(f32_passes, f32_one)
+    import torch
+    dev = torch.device("cuda", 0)
+    tpr = rt.tiles_per_rank(96, 54, 3)
+    gathered = torch.zeros((3, tpr, 3, 64), dtype=torch.float64, device=dev)
+    for rank in range(3):
+        renderer.render_device(cam, gathered[rank].data_ptr(), 0, rank=rank, n_ranks=3)
+    image = torch.zeros((54, 96, 3), dtype=torch.float64, device=dev)
+    renderer.unpermute(96, 54, 3, rt.RTK_REAL_F64, gathered.data_ptr(), image.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert np.array_equal(image.cpu().numpy(), passes)
+
+
 FULL_SIZE_CONFIGS = [
     # config, scene, (W, H, spp, depth), substring of the timed kernel's name
     ("c3", "cornell_box", (800, 800, 1000, 25), "837u"),
@@ -406,8 +440,7 @@ def test_device_hit_records_match_reference_known_answers(rt, renderer, tmp_path
     assert n_exact >= 0.95 * n_hits   # nearly all records are bit-identical; the rest differ by log()/ulps in media
 
 
-# ---- the fast visiting order (rtk_scene_optimize, SURVEY.md 8(f) rank 1) --------------------------------------
-@pytest.mark.parametrize("case", IMAGE_CASES, ids=[c[0] for c in IMAGE_CASES])
+# ---- function-level known answers for the shading side (rtk_debug_scatter / _texture / _get_ray) ----------------
 def _load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
@@ -474,6 +507,8 @@ def test_device_get_ray_matches_reference_known_answers(rt, renderer):
         assert np.array_equal(draws.astype(np.int64), meta[rows][:, 4].astype(np.int64))
 
 
+# ---- the fast visiting order (rtk_scene_optimize, SURVEY.md 8(f) rank 1) --------------------------------------
+@pytest.mark.parametrize("case", IMAGE_CASES, ids=[c[0] for c in IMAGE_CASES])
 def test_fast_order_on_the_device(rt, orc, renderer, scenes, case):
     """The re-grouped hierarchy through the same kernels: the device agrees with the oracle executing that
     hierarchy (image, bytes, every work counter), and -- where the pass claims exactness, and on the triangle

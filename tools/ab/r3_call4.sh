@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 3, GPU call 4: the whole GPU suite, then current vs the round-2 kernel library on every config.
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
+timeout -k 10 1100 python -m pytest tests -m gpu -q > gpurun_out/r3_call4_tests.log 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/r3_call4_tests.log
+grep -E "passed|failed|^FAILED|^ERROR" gpurun_out/r3_call4_tests.log | tail -20
+cat gpurun_out/full_size_sha_*.json 2>/dev/null; echo
+for cfg in c2:0 c3:100 c4:64 c5:32; do
+  AB_CONFIG=${cfg%%:*} AB_SPP=${cfg##*:} timeout -k 10 400 tools/ab/run_built.sh r02 current 2>&1 | grep -v amdgpu.ids | cut -c1-120 | tee -a gpurun_out/r3_call4_ab.log
+done

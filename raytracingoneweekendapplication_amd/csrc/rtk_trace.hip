@@ -455,7 +455,6 @@ struct Lane {
 #endif
     float tmin32, tmax32;
     V3<float> inv32s, oi32s; // lean MIXED kernel (RTK_CH_SCALED): inv32 and oi32 times 1 / (end of the current interval), see rescale32
-    V3<float> ainv32s;       // RTK_PK_BOX: |inv32s| (a packed instruction has no |.| source modifier)
     float m2slack32;         // COMPACT kernels with centre / half-extent boxes: -2 x the ray's slack (slab_test32_che)
     real a, inv_a, tm;       // d.d (sphere.h:35, hoisted likewise) and 1/(d.d) for divide_by; ray time
     real tmin, best_t;       // current query interval: (tmin, closest so far)
@@ -593,9 +592,6 @@ RTK_DEV void rescale32(Lane<real>& L, float extent) {
     const float s = __builtin_amdgcn_rcpf(end) * 0.99999976f;
     L.inv32s = V3<float>{L.inv32.x * s, L.inv32.y * s, L.inv32.z * s};
     L.oi32s = V3<float>{L.oi32.x * s, L.oi32.y * s, L.oi32.z * s};
-#if RTK_PK_BOX
-    L.ainv32s = V3<float>{__builtin_fabsf(L.inv32s.x), __builtin_fabsf(L.inv32s.y), __builtin_fabsf(L.inv32s.z)};
-#endif
 }
 // A primitive test accepted t: it is the closest hit so far (hittable_list.h:27-31 / bvh.h:69 shrink the interval).
 template <bool MIXED, bool SCALED = false, typename real>
@@ -734,21 +730,11 @@ RTK_DEV void step_box32_che(Lane<real>& L, const MixedHead& rec, Counters<COUNT>
 // clamped to the same end -- the box lies wholly before 0 or wholly beyond 1.
 RTK_DEV float max3_clamp01(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 RTK_DEV float min3_clamp01(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-// ... with packed f32 arithmetic (RTK_PK_BOX, A/B): v_pk_fma_f32 computes two fused multiply-adds per lane and instruction --
-// the centre terms of x and y in one, then per axis the pair (near, far) = (tc - h |inv|, tc + h |inv|) in one: five
-// instructions instead of nine.  |inv| cannot be a source modifier of a packed instruction: the lane keeps it (ainv32s).
-#ifndef RTK_PK_BOX
-#define RTK_PK_BOX 0
-#endif
-typedef float pk2f __attribute__((ext_vector_type(2)));
-RTK_DEV bool slab_test32_chs_pk(const MixedHead& b, V3<float> oi, V3<float> inv, V3<float> ainv) {
-    const pk2f tcxy = __builtin_elementwise_fma(pk2f{b.f(0), b.f(1)}, pk2f{inv.x, inv.y}, pk2f{-oi.x, -oi.y});
-    const float tcz = __builtin_fmaf(b.f(2), inv.z, -oi.z);
-    const pk2f nfx = __builtin_elementwise_fma(pk2f{-b.f(3), b.f(3)}, pk2f{ainv.x, ainv.x}, pk2f{tcxy.x, tcxy.x});
-    const pk2f nfy = __builtin_elementwise_fma(pk2f{-b.f(4), b.f(4)}, pk2f{ainv.y, ainv.y}, pk2f{tcxy.y, tcxy.y});
-    const pk2f nfz = __builtin_elementwise_fma(pk2f{-b.f(5), b.f(5)}, pk2f{ainv.z, ainv.z}, pk2f{tcz, tcz});
-    return min3_clamp01(nfx.y, nfy.y, nfz.y) > max3_clamp01(nfx.x, nfy.x, nfz.x);
-}
+// (Packed f32 arithmetic for this test was measured in round 3 and removed: five v_pk_fma_f32 with op_sel / neg modifiers
+// (inline asm on aligned register pairs: no moves) instead of nine v_fma_f32 -- 12 instead of 16 VALU instructions per box
+// step in the ISA, same bits, same image -- ran C2 at 19.35 instead of 18.50 ms: the packed instruction issues at 0.51 per
+// cycle against 0.68 for v_fma_f32 (csrc/rtk_microbench.hip) and lengthens the step's dependent chain, which is what the
+// step waits for.  Left to the compiler (ext_vector_type(2) fma) the same test cost 9-19 extra moves per step: 22.6 ms.)
 RTK_DEV bool slab_test32_chs(const MixedHead& b, V3<float> oi, V3<float> inv) {
     const float tcx = __builtin_fmaf(b.f(0), inv.x, -oi.x), tcy = __builtin_fmaf(b.f(1), inv.y, -oi.y), tcz = __builtin_fmaf(b.f(2), inv.z, -oi.z);
     const float ax = __builtin_fabsf(inv.x), ay = __builtin_fabsf(inv.y), az = __builtin_fabsf(inv.z);
@@ -760,9 +746,7 @@ RTK_DEV bool slab_test32_chs(const MixedHead& b, V3<float> oi, V3<float> inv) {
 template <typename real, bool COUNT>
 RTK_DEV void step_box32_ch(Lane<real>& L, const MixedHead& rec, Counters<COUNT>& cnt) {
     cnt.inc(C_BOX);
-#if RTK_CH_SCALED && RTK_PK_BOX
-    const bool hit = slab_test32_chs_pk(rec, L.oi32s, L.inv32s, L.ainv32s);
-#elif RTK_CH_SCALED
+#if RTK_CH_SCALED
     const bool hit = slab_test32_chs(rec, L.oi32s, L.inv32s);
 #else
     const bool hit = slab_test32_ch(rec, L.oi32, L.inv32, L.tmin32, L.tmax32);
@@ -2164,6 +2148,10 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_ke
             // neighbours in the program, an instance is entered and left through two chain switches -- was measured and
             // removed in round 3: C5 42.55 vs 42.10 ms at 32 spp, C4 15.47 vs 15.38, and the quad/box kernel lost 27 % to it,
             // C3 33.6 vs 26.3 ms at 100 spp.)
+            // (Also measured and removed in round 3: the two sphere-bounded media of book 2 -- neighbours in the program, met by
+            // every segment -- evaluated side by side in ONE branch-free step so that their two chains of dependent f64
+            // operations interleave, B's random number drawn speculatively from the state A leaves: same image, same
+            // counters, C5 42.9 vs 41.9 ms at 32 spp.)
             if (m_oth >> lane & 1ull) {
                 if constexpr (MIXED && !COMPACT) step_other_mixed<kPcUnit>(L, rec_at(L.pc), cnt, tie, extent);
                 else step_other<real, FEAT, COUNT>(L, prog + L.pc, sc, cnt, tie, extent);

@@ -962,6 +962,42 @@ RTK_DEV real perlin_noise(const PerlinRec<real>& pn, V3<real> p, Counters<COUNT>
     return accum;
 }
 
+// get_sphere_uv (sphere.h:67-73) and noise_texture::value's tail (texture.h:114-116: 1 + sin(...)) are libm-heavy f64 code
+// (acos, atan2, sin: long polynomial expansions) that few lanes ever reach; inlined into the shade step they sit on top of
+// everything live there and account for most of the full-feature kernel's scratch (compile-only ablation,
+// tools/kernel_resources.py: without the two 248 VGPRs and no scratch at the 2-wave bound, with them 256 + 292 B).  Kept OUT
+// OF LINE (RTK_COLD_UV / RTK_COLD_NOISE) a call saves and restores around itself on the cold path only: 248 VGPRs + 32 B at
+// two waves per SIMD, 168 + 352 B at three (it was 168 + 640 B) -- and three waves then win: C5 at 32 spp 42.05 ms (inline,
+// 2 waves) -> 40.5 (out of line, 2 waves) -> 38.85 (out of line, 3 waves); out of line at 3 waves with only the uv function
+// moved: 47.3.  Same image.  (Moving more -- pow, perlin::turb, the image lookup, get_lighting, the media's log -- was
+// measured too and lost: 43.0-46.7 ms at three waves.)
+#ifndef RTK_COLD_UV
+#define RTK_COLD_UV 1
+#endif
+#ifndef RTK_COLD_NOISE
+#define RTK_COLD_NOISE 1
+#endif
+#if RTK_COLD_UV
+#define RTK_UV_FN __device__ __attribute__((noinline))
+#else
+#define RTK_UV_FN RTK_DEV
+#endif
+#if RTK_COLD_NOISE
+#define RTK_NOISE_FN __device__ __attribute__((noinline))
+#else
+#define RTK_NOISE_FN RTK_DEV
+#endif
+template <typename real>
+RTK_UV_FN void sphere_uv(real ox, real oy, real oz, real* __restrict__ uv) {  // sphere.h:67-73 on the outward unit normal
+    const real pi = real(3.1415926535897932385);
+    const real theta = rt_acos(-oy);
+    const real phi = rt_atan2(-oz, ox) + pi;
+    uv[0] = phi / (real(2) * pi);
+    uv[1] = theta / pi;
+}
+template <typename real>
+RTK_NOISE_FN real noise_tail(real arg) { return real(1) + rt_sin(arg); }  // texture.h:115: 1 + sin(scale * p.z + 10 * turb)
+
 // texture::value (texture.h:20-120); checker nesting is followed iteratively.
 template <typename real, bool COUNT>
 RTK_DEV V3<real> texture_value(const SceneView<real>& sc, int tex, real u, real v, V3<real> p, Counters<COUNT>& cnt) {
@@ -1006,7 +1042,7 @@ RTK_DEV V3<real> texture_value(const SceneView<real>& sc, int tex, real u, real 
             weight *= real(0.5);
             q = mk(q.x * real(2), q.y * real(2), q.z * real(2));
         }
-        const real s = real(1) + rt_sin(t.param * p.z + real(10) * rt_fabs(accum));
+        const real s = noise_tail(t.param * p.z + real(10) * rt_fabs(accum));
         return mk(s * real(0.5), s * real(0.5), s * real(0.5));
     }
 }
@@ -1093,11 +1129,10 @@ RTK_DEV void make_surface(const Rec* __restrict__ prog, const SceneView<real>& s
         if (kind == OP_SPHERE_MOVING) cc = cc + scale(tm, moving_dir<real>(rec));
         outward = scale(packed<real, 4>(rec), sf.p - cc);  // (p - center) / radius = (1/radius) * (p - center) (vec3.h:91-93); element 4 = 1/radius from the upload
         if ((FEAT & F_TEXTURE) && (force_uv || mats[sf.material].needs_uv)) {
-            const real pi = real(3.1415926535897932385);
-            real theta = rt_acos(-outward.y);
-            real phi = rt_atan2(-outward.z, outward.x) + pi;
-            sf.u = phi / (real(2) * pi);
-            sf.v = theta / pi;
+            real uv[2];
+            sphere_uv(outward.x, outward.y, outward.z, uv);
+            sf.u = uv[0];
+            sf.v = uv[1];
         }
     } else if ((FEAT & F_QUAD) && kind == OP_QUAD) {  // quad.h:44-57; record = n(3),D,Q(3),w(3),v(3),u(3)
         V3<real> planar = sf.p - packed3<real, 4>(rec);
@@ -1430,7 +1465,7 @@ RTK_DEV void store_partial(real* __restrict__ partial, int item, int pix, V3<rea
 #define RTK_SPLIT_MATERIALS_IN_LDS 1
 #endif
 #ifndef RTK_THREADS_ALL_F64
-#define RTK_THREADS_ALL_F64 512   // workgroup bound of the full-feature f64 kernel (A/B builds: 768 = 3 waves per SIMD, 1024 = 4)
+#define RTK_THREADS_ALL_F64 768   // workgroup bound of the full-feature f64 kernels: 3 waves per SIMD, 168 VGPRs (A/B builds: 512 = 2 waves, 1024 = 4)
 #endif
 // Workgroup-size bound = register budget: 1024 threads -> 4 waves per SIMD, 128 VGPRs; 768 -> 3 waves, 168 VGPRs;
 // 512 -> 2 waves, 256 VGPRs.  Measured on C2 (lean f64 kernel): 2 waves 93.8 ms, 3 waves 73.5 ms, 4 waves 68.5 ms

@@ -77,6 +77,31 @@ RTK_DEV double rt_atan2(double y, double x) { return atan2(y, x); }
 RTK_DEV float rt_atan2(float y, float x) { return atan2f(y, x); }
 
 template <typename real> RTK_DEV real real_inf() { return real(__builtin_huge_val()); }
+// Round 3: libm-heavy f64 code kept OUT OF LINE, one macro each (see sphere_uv below for the reasoning and the first two).
+// Measured and left inline: perlin::noise (43.7 vs 34.0 ms) and texture::value as a whole (864 B of scratch).
+#ifndef RTK_COLD_POW
+#define RTK_COLD_POW 1   // pow (the specular material): C5 38.87 -> 38.25 ms at 32 spp
+#endif
+#ifndef RTK_COLD_LOG
+#define RTK_COLD_LOG 1   // log (constant_medium's scatter distance, twice per segment in book 2): 38.87 -> 35.72; both: 33.98
+#endif
+#ifndef RTK_COLD_PERLIN
+#define RTK_COLD_PERLIN 0
+#endif
+#ifndef RTK_COLD_TEX
+#define RTK_COLD_TEX 0
+#endif
+#define RTK_NOINLINE __device__ __attribute__((noinline))
+#if RTK_COLD_POW
+template <typename real> RTK_NOINLINE real call_pow(real x, real y) { return rt_pow(x, y); }
+#else
+template <typename real> RTK_DEV real call_pow(real x, real y) { return rt_pow(x, y); }
+#endif
+#if RTK_COLD_LOG
+template <typename real> RTK_NOINLINE real call_log(real x) { return rt_log(x); }
+#else
+template <typename real> RTK_DEV real call_log(real x) { return rt_log(x); }
+#endif
 
 // v_min/v_max as single instructions.  __builtin_fmin/fmax are IEEE minnum/maxnum, for which the
 // compiler first canonicalises every operand it cannot prove quiet (an extra v_max x,x per use).
@@ -877,7 +902,7 @@ RTK_DEV void step_other(Lane<real>& L, const Rec* __restrict__ rec, const SceneV
                     if (r1 < real(0)) r1 = real(0);
                     const real ray_length = rt_sqrt(L.a);
                     const real inside = (r2 - r1) * ray_length;
-                    const real hit_distance = packed<real, 4>(rec) * rt_log(rnd<real>(L.rng, cnt));
+                    const real hit_distance = packed<real, 4>(rec) * call_log(rnd<real>(L.rng, cnt));
                     if (!(hit_distance > inside)) take_hit<MIXED>(L, r1 + hit_distance / ray_length);
                 }
             }
@@ -921,7 +946,7 @@ RTK_DEV void step_other(Lane<real>& L, const Rec* __restrict__ rec, const SceneV
                 if (r1 < real(0)) r1 = real(0);
                 const real ray_length = rt_sqrt(L.a);
                 const real inside = (r2 - r1) * ray_length;
-                const real hit_distance = packed<real, 0>(rec) * rt_log(rnd<real>(L.rng, cnt));
+                const real hit_distance = packed<real, 0>(rec) * call_log(rnd<real>(L.rng, cnt));
                 if (!(hit_distance > inside)) {
                     L.best_t = r1 + hit_distance / ray_length;
                     L.best_pc = L.pc;
@@ -937,8 +962,13 @@ RTK_DEV void step_other(Lane<real>& L, const Rec* __restrict__ rec, const SceneV
 
 // ------------------------------------------------------------------ textures --
 // perlin::noise (perlin.h:14-37,72-89).
+#if RTK_COLD_PERLIN
+#define RTK_PERLIN_FN RTK_NOINLINE
+#else
+#define RTK_PERLIN_FN RTK_DEV
+#endif
 template <typename real, bool COUNT>
-RTK_DEV real perlin_noise(const PerlinRec<real>& pn, V3<real> p, Counters<COUNT>& cnt) {
+RTK_PERLIN_FN real perlin_noise(const PerlinRec<real>& pn, V3<real> p, Counters<COUNT>& cnt) {
     cnt.inc(C_NOISE);
     const real fx = rt_floor(p.x), fy = rt_floor(p.y), fz = rt_floor(p.z);
     const real u = p.x - fx, v = p.y - fy, w = p.z - fz;
@@ -999,8 +1029,13 @@ template <typename real>
 RTK_NOISE_FN real noise_tail(real arg) { return real(1) + rt_sin(arg); }  // texture.h:115: 1 + sin(scale * p.z + 10 * turb)
 
 // texture::value (texture.h:20-120); checker nesting is followed iteratively.
+#if RTK_COLD_TEX
+#define RTK_TEX_FN RTK_NOINLINE
+#else
+#define RTK_TEX_FN RTK_DEV
+#endif
 template <typename real, bool COUNT>
-RTK_DEV V3<real> texture_value(const SceneView<real>& sc, int tex, real u, real v, V3<real> p, Counters<COUNT>& cnt) {
+RTK_TEX_FN V3<real> texture_value(const SceneView<real>& sc, int tex, real u, real v, V3<real> p, Counters<COUNT>& cnt) {
     for (;;) {
         const TextureRec<real>& t = sc.textures[tex];
         if (t.kind == RTK_TEX_SOLID) return ld3(t.color);
@@ -1293,7 +1328,7 @@ RTK_DEV bool shade_surface(Lane<real>& L, const Surface<real>& sf, const SceneVi
         const V3<real> refl = reflect(unit_d, sf.normal);
         V3<real> diffuse = random_unit_vector<real>(L.rng, cnt);  // random_on_hemisphere, vec3.h:116-124
         if (!(dot(diffuse, sf.normal) > real(0))) diffuse = -diffuse;
-        const real f = rt_pow(real(1) - dot(refl, unit_d), m.param);
+        const real f = call_pow(real(1) - dot(refl, unit_d), m.param);
         V3<real> dir = scale(f, refl) + scale(real(1) - f, diffuse);
         if (near_zero(dir)) dir = sf.normal;
         next_d = dir;

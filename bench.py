@@ -631,10 +631,13 @@ def main():
                                 "issue_cycles_per_wave_instruction": cycles, "issue_cycles_source": cycles_source,
                                 "issue_rates_measured": {k: round(v, 4) for k, v in measured.items() if k.startswith("issue_")} if measured else None}
         if measured:
-            lds_rate = measured["lds_read_b128_random_GBps"]
+            lds_rate = measured["lds_read_b128_GBps"]
             hbm_model["model_vs_lds_ceiling"] = round(model_gbs / lds_rate, 4) if lds_rate > 0 else None
             hbm_model["lds_ceiling_GBps"] = round(lds_rate, 1)
-            hbm_model["note"] += "; model_vs_lds_ceiling = model_GBps / the measured ds_read_b128 rate on random 32-byte records (what the box step reads)"
+            hbm_model["lds_random_record_probe_GBps"] = round(measured["lds_read_b128_random_GBps"], 1)
+            hbm_model["note"] += ("; model_vs_lds_ceiling = model_GBps / the measured conflict-free ds_read_b128 rate of the chip (every lane its own 16 bytes); "
+                                  "lds_random_record_probe_GBps = a probe reading per-lane random 32-byte records behind an address computation of its own "
+                                  "(bank conflicts included) -- a lower bound of the random-record rate, not a ceiling")
         # the work-based fraction: exact work counters x ISA-derived cost per unit of work (lean MIXED kernel family)
         isa, isa_why = load_isa_costs()
         if isa is not None and mixed:

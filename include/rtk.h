@@ -214,7 +214,7 @@ typedef struct rtk_render_opts {
                              * buffer [tiles][3][64] also when n_ranks == 1 (rtk_multi's one-device RCCL path; d_rgb8 NULL);
                              * bit 23 = the hot/cold form of a COMPACT program (quads and triangles in memory, the rest in
                              * LDS) although the whole program would fit (tests); bit 24 = render every sample chunk in ONE
-                             * launch with a partial-sum plane per chunk (up to 64) instead of passes of 16 chunks whose running
+                             * launch with a partial-sum plane per chunk (up to 64) instead of passes of 21 chunks whose running
                              * sum the resolve kernel carries (tests: the same additions in the same order, the same image) */
     void* stream;           /* hipStream_t, NULL = default stream */
 } rtk_render_opts;

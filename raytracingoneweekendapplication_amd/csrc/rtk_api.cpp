@@ -957,9 +957,12 @@ struct rtk_ctx {
     bool progress_pending = false;
 };
 // Sample chunks per launch: the partial-sum workspace holds this many planes [local tile][3][64] (+ one for the running sum
-// of a frame that needs several launches).  1920x1080: 16 planes of f64 = 0.8 GB, where the 63 chunks of a 1000-spp frame
-// used to take 3.1 GB per context (and 6.3 GB of write + read traffic per frame).
-constexpr int kMaxPlanesPerPass = 16;
+// of a frame that needs several launches).  1920x1080 in f64: 21 + 1 planes = 1.09 GB, where the 63 chunks of a 1000-spp
+// frame used to take 3.14 GB per context.  Every launch has a fixed cost -- staging the program, the drain of its last long
+// paths -- measured on the full-size frames (same box, same image): one launch / passes of 16 chunks: C5 999.6 / 1014.6 ms,
+// C3 247.7 / 254.5 ms; 21 chunks per pass makes a 1000-spp frame three launches instead of four.  Frames of up to 168 spp
+// (C2: 13 chunks) are one launch as before.
+constexpr int kMaxPlanesPerPass = 21;
 constexpr int kMaxPasses = (rtk::kMaxChunks + kMaxPlanesPerPass - 1) / kMaxPlanesPerPass;
 static_assert(kMaxPasses <= 4, "rtk_ctx keeps four pass counters");
 constexpr unsigned int kCounterRing = 256;

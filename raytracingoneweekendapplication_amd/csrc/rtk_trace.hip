@@ -1139,6 +1139,26 @@ RTK_DEV void make_surface_mixed(const MixedHead* __restrict__ prog, uint32_t bes
 }
 
 
+// The barycentrics of the winning triangle for its UVs (triangle.h:96-110): triangle::hit once more on the winner, with an
+// open interval.  RTK_COLD_TRI_UV keeps it out of line (A/B: the mesh kernels at four waves per SIMD).
+#ifndef RTK_COLD_TRI_UV
+#define RTK_COLD_TRI_UV 0
+#endif
+#if RTK_COLD_TRI_UV
+#define RTK_TRI_UV_FN RTK_NOINLINE
+#else
+#define RTK_TRI_UV_FN RTK_DEV
+#endif
+template <typename real, typename Rec>
+RTK_TRI_UV_FN void tri_barycentrics(const Rec* __restrict__ rec, real ox, real oy, real oz, real dx, real dy, real dz, float* fa, float* fb, float* fg) {
+    real tt;
+    float a = 0, b = 0, g = 0;
+    tri_test(rec, mk(ox, oy, oz), mk(dx, dy, dz), -real_inf<real>(), real_inf<real>(), tt, a, b, g);
+    *fa = a;
+    *fb = b;
+    *fg = g;
+}
+
 // Build the hit record of the winning record (the deferred half of *.hit).  Sphere
 // and quad geometry is read from the program record itself (LDS when staged); only
 // triangles go to their side record for the normal and the UVs.  `prog` is the slot
@@ -1179,7 +1199,7 @@ RTK_DEV void make_surface(const Rec* __restrict__ prog, const SceneView<real>& s
         const TriRec<real>& tr = sc.tris[idx];
         real tt;
         float fa = 0, fb = 0, fg = 0;
-        tri_test(rec, o, d, -real_inf<real>(), real_inf<real>(), tt, fa, fb, fg);
+        tri_barycentrics(rec, o.x, o.y, o.z, d.x, d.y, d.z, &fa, &fb, &fg);
         sf.u = real(fa * tr.uv0[0] + fb * tr.uv1[0] + fg * tr.uv2[0]);
         sf.v = real(fa * tr.uv0[1] + fb * tr.uv1[1] + fg * tr.uv2[1]);
         outward = ld3(tr.n);
@@ -1507,19 +1527,31 @@ RTK_DEV void store_partial(real* __restrict__ partial, int item, int pix, V3<rea
 // per frame (the 4-wave build spills a few values in the shade path).  Same-box A/B for the other f64 kernels
 // (tools/ab/run_ab.sh): quad/box subset on C3 43.3 ms at 4 waves vs 48.7 at 3; mesh subset on C4 no difference;
 // the full-feature kernel, which needs far more registers (~560 B/lane of spills at 168), is fastest at 2 waves.
+#ifndef RTK_THREADS_MESH_F64
+#define RTK_THREADS_MESH_F64 1024   // workgroup bound of the f64 mesh kernels: 4 waves per SIMD, 128 VGPRs (C4 60.1 -> 53.0 ms; 768 = 3 waves)
+#endif
+// (round 3) the f64 mesh kernels run at four waves per SIMD when the whole program is staged in LDS (C4 60.1 -> 53.0 ms, 44 B of
+// scratch); with the program, or all but its boxes, in memory a fourth wave only adds pressure on L2 (C4, program in global
+// memory: 23.2 ms at three waves, 33.6 at four), so those keep 768 threads.
 template <typename real>
-constexpr int max_threads_of(uint32_t feat) {
+constexpr int max_threads_of(uint32_t feat, bool in_lds) {
     const uint32_t scene_feat = feat & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE | F_LDS_BOXES);
-    if (sizeof(real) == 8) return scene_feat == kFeatAll ? RTK_THREADS_ALL_F64 : ((scene_feat == kFeatLean || scene_feat == kFeatQuadBox) ? 1024 : 768);
+    // ... and the full-feature f64 kernels run at three waves where the traversal data is in LDS -- the whole program, or the
+    // hot part of a COMPACT program (F_LDS_BOXES | F_F32_BOX: C5 at 16 spp 21.1 -> 17.7 ms) -- and stay at two where records
+    // come from memory (program in global memory 25.5 vs 29.1 ms at three; slot program with its boxes in LDS 25.6 vs 29.0).
+    const bool hot_cold = (feat & F_LDS_BOXES) != 0 && (feat & F_F32_BOX) != 0;
+    if (sizeof(real) == 8)
+        return scene_feat == kFeatAll ? ((in_lds || hot_cold) ? RTK_THREADS_ALL_F64 : 512)
+                                      : ((scene_feat == kFeatLean || scene_feat == kFeatQuadBox) ? 1024 : (in_lds ? RTK_THREADS_MESH_F64 : 768));
     return 768;
 }
-template <typename real, uint32_t FEAT>
+template <typename real, uint32_t FEAT, bool IN_LDS>
 constexpr int max_threads() {
-    return max_threads_of<real>(FEAT);
+    return max_threads_of<real>(FEAT, IN_LDS);
 }
 
 template <typename real, uint32_t FEAT_ALL, bool COUNT, bool IN_LDS>
-__global__ __launch_bounds__((max_threads<real, FEAT_ALL>())) void rtk_render_kernel(SceneView<real> sc, const CameraRec<real>* __restrict__ cam_ptr, TileMap tmap, uint32_t seed,
+__global__ __launch_bounds__((max_threads<real, FEAT_ALL, IN_LDS>())) void rtk_render_kernel(SceneView<real> sc, const CameraRec<real>* __restrict__ cam_ptr, TileMap tmap, uint32_t seed,
                                                           real* __restrict__ partial, unsigned long long* __restrict__ counters,
                                                           unsigned int* __restrict__ tile_counter, const int32_t* __restrict__ tile_order,
                                                           unsigned int* __restrict__ tile_cost, uint32_t diag) {
@@ -2610,7 +2642,7 @@ static hipError_t launch_one(const SceneView<real>& sc, const CameraRec<real>* c
         lds = size_t(tm.order_lds_offset) + order_bytes;
     }
     int blocks = 0, threads = 0;
-    hipError_t e = plan_launch(kernel, max_threads<real, FEAT>() / 64, lds, n_items, blocks, threads);
+    hipError_t e = plan_launch(kernel, max_threads<real, FEAT, IN_LDS>() / 64, lds, n_items, blocks, threads);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(tile_counter, 0, sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;

@@ -331,13 +331,13 @@ def test_config4_and_config5_full_resolution_reduced_spp_properties(rt, orc, ren
 
 
 def test_frames_with_many_sample_chunks_are_rendered_in_passes_with_the_same_sums(rt, orc, renderer, scenes):
-    """More than 16 sample chunks (spp > 128): the frame is rendered in passes of 16 chunks, the resolve kernel carrying every
-    pixel's running sum from pass to pass, so that the partial-sum workspace stays at 17 planes (1000 spp used to take 63).
+    """More than 21 sample chunks (spp > 168): the frame is rendered in passes of 21 chunks, the resolve kernel carrying every
+    pixel's running sum from pass to pass, so that the partial-sum workspace stays at 22 planes (1000 spp used to take 63).
     The additions are those of one pass over all chunks, in the same order: the image must be the one-launch image (variant
     bit 24) bit for bit -- whole, sharded over ranks, in float -- and the oracle's within rounding; progress reports of a
     blocking render add the passes up monotonically."""
     scene = scenes("book1_final")
-    cam = scene.camera(96, 54, 8 * 37, 12)           # 37 chunks of 8 samples: passes of 16 + 16 + 5
+    cam = scene.camera(96, 54, 8 * 47, 12)           # 47 chunks of 8 samples: passes of 21 + 21 + 5
     renderer.upload_fast(scene, cam.center)
     seen = []
     renderer.set_progress(lambda done, total: seen.append((done, total)), interval_ms=1)
@@ -345,7 +345,7 @@ def test_frames_with_many_sample_chunks_are_rendered_in_passes_with_the_same_sum
     renderer.set_progress(None)
     one, one8, _ = renderer.render_host(cam, variant=1 << 24)
     assert np.array_equal(passes, one) and np.array_equal(passes8, one8)
-    n_items = -(-96 // 8) * -(-54 // 8) * 37
+    n_items = -(-96 // 8) * -(-54 // 8) * 47
     assert seen and seen[-1] == (n_items, n_items) and all(0 <= a[0] <= b[0] <= b[1] for a, b in zip(seen, seen[1:]))
     ref, ref8, _ = orc.render(scene.desc_ptr, cam, RENDER_SEED, 8)
     assert np.sqrt(np.mean((passes - ref) ** 2)) < 1e-12 and np.array_equal(passes8, ref8)

@@ -610,7 +610,9 @@ def main():
                      "per_sample": {k: round(counters[k] / counters["samples"], 4) for k in rt.COUNTER_FIELDS if k != "samples"}}
         rec, why = (None, "reduced workload: PMC profiles exist for the full-size configs only") if reduced or args.variant else load_pmc(args.config, kernel, workload, n)
         roofline = {"bound": "valu", "achieved": None, "peak": round(N_SIMDS * MAX_CLOCK_GHZ, 1), "unit": "G VALU pipe-cycles/s", "frac": None, "traffic": None,
-                    "kernel": kernel, "kernel_ms": round(kernel_ms, 4)}
+                    "kernel": kernel, "kernel_ms": round(kernel_ms, 4),
+                    # a frame with more than 21 sample chunks (spp > 168) is several launches of the kernel; kernel_ms and every counter are per FRAME
+                    "launches_per_frame": rt.hip_lib().rtk_frame_launches(spp, args.variant)}
         # measured ceilings of THIS box (csrc/rtk_microbench.hip): achievable HBM rate from a stream copy, the LDS
         # read rate the byte model is served at, and the issue cost of each VALU class the roofline prices
         measured, measured_why = None, None

@@ -465,6 +465,11 @@ int rtk_debug_get_ray(rtk_ctx* ctx, int real_mode, const rtk_camera* cam, uint32
  * for the byte model): number of program slots (fused records) and device bytes per mode. */
 int rtk_scene_info(rtk_ctx* ctx, int32_t* n_program_ops, int64_t* bytes_f64, int64_t* bytes_f32);
 
+/* Render-kernel launches one frame takes (host-only): a pixel's samples are split into chunks of 8 (at most 64 chunks),
+ * and a frame with more than 21 chunks is rendered in consecutive passes over the chunks whose running sums the resolve
+ * kernel carries -- the image is the same for any number of passes.  1 up to 168 samples per pixel, 3 at 1000. */
+int rtk_frame_launches(int samples_per_pixel, int variant);
+
 /* Names of the kernel symbols rtk_render_device launches for (real_mode,
  * variant) on the uploaded scene -- used to find the dispatch in rocprofv3
  * traces.  Returns a static string. */

@@ -964,6 +964,14 @@ struct rtk_ctx {
 // (C2: 13 chunks) are one launch as before.
 constexpr int kMaxPlanesPerPass = 21;
 constexpr int kMaxPasses = (rtk::kMaxChunks + kMaxPlanesPerPass - 1) / kMaxPlanesPerPass;
+// Samples per chunk: 8, or the smallest size that keeps a pixel's chunks within kMaxChunks -- a function of spp only.
+static int chunk_size_for(int spp, int variant) {
+    const int ab = (variant >> 3) & 3;  // tools/: chunk size A/B (0 = default 8, 1 = 4, 2 = 2, 3 = 16)
+    int size = ab == 0 ? 8 : (ab == 1 ? 4 : (ab == 2 ? 2 : 16));
+    if (variant & 2) size = spp;  // variant bit 1: one lane per pixel for all samples (tests)
+    while ((spp + size - 1) / size > rtk::kMaxChunks) size++;
+    return size;
+}
 static_assert(kMaxPasses <= 4, "rtk_ctx keeps four pass counters");
 constexpr unsigned int kCounterRing = 256;
 constexpr size_t kCameraStride = 256;
@@ -1271,10 +1279,7 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
         const int spp = cam->samples_per_pixel;
         int n = 0;
         tm.chunk_start[0] = 0;
-        const int ab = (opts->variant >> 3) & 3;  // tools/: chunk size A/B (0 = default 8, 1 = 4, 2 = 2, 3 = 16)
-        int size = ab == 0 ? 8 : (ab == 1 ? 4 : (ab == 2 ? 2 : 16));
-        if (opts->variant & 2) size = spp;  // variant bit 1: one lane per pixel for all samples (tests)
-        while ((spp + size - 1) / size > kMaxChunks) size++;
+        const int size = chunk_size_for(spp, opts->variant);
         for (int s0 = size; s0 < spp; s0 += size) tm.chunk_start[++n] = int16_t(s0);
         tm.chunk_start[++n] = int16_t(spp);
         tm.n_chunks = n;
@@ -1552,6 +1557,14 @@ int rtk_debug_get_ray(rtk_ctx* ctx, int real_mode, const rtk_camera* cam, uint32
     b.back(reinterpret_cast<unsigned long long*>(h_draws), d_draws, size_t(n));
     if (b.err != hipSuccess) return fail(RTK_ERR_HIP, "rtk_debug_get_ray: %s", hipGetErrorString(b.err));
     return RTK_OK;
+}
+
+int rtk_frame_launches(int samples_per_pixel, int variant) {
+    if (samples_per_pixel <= 0 || samples_per_pixel > 32767) return fail(RTK_ERR_INVALID, "rtk_frame_launches: samples_per_pixel must be 1..32767");
+    const int size = chunk_size_for(samples_per_pixel, variant);
+    const int chunks = (samples_per_pixel + size - 1) / size;
+    const int per_pass = (variant & (1 << 24)) ? rtk::kMaxChunks : kMaxPlanesPerPass;
+    return (chunks + per_pass - 1) / per_pass;
 }
 
 int rtk_scene_info(rtk_ctx* ctx, int32_t* n_program_ops, int64_t* bytes_f64, int64_t* bytes_f32) {

@@ -2359,7 +2359,10 @@ __global__ __launch_bounds__(256) void rtk_debug_scatter_kernel(SceneView<real> 
     sf.u = real(h[8]);
     sf.v = real(h[9]);
     sf.material = mat[gid];
-    const bool ended = shade_surface<real, kFeatAll>(L, sf, sc, sc.materials, cnt);
+#ifdef RTK_PROFILE
+    ShadeProf sprof;  // (the profile build's shade functions take their sub-phase accumulators)
+#endif
+    const bool ended = shade_surface<real, kFeatAll>(L, sf, sc, sc.materials, cnt RTK_SHADE_PROF_ARG);
     double* o = out + size_t(gid) * 14;
     o[0] = ended ? 0.0 : 1.0;
     o[1] = double(L.ro.x); o[2] = double(L.ro.y); o[3] = double(L.ro.z);
@@ -2906,7 +2909,10 @@ __global__ __launch_bounds__(1024) void rtk_isa_probe(Lane<double>* __restrict__
         Surface<double> sf;
         make_surface_mixed(rec, 0u, L.best_t, L.ro, L.rd, L.tm, sf);
         constexpr int kMat = KIND == PROBE_LAMBERTIAN ? int(RTK_MAT_LAMBERTIAN) : (KIND == PROBE_METAL ? int(RTK_MAT_METAL) : int(RTK_MAT_DIELECTRIC));
-        const bool ended = shade_surface<double, kProbeFeat, kMat>(L, sf, sc, sc.materials, cnt);
+#ifdef RTK_PROFILE
+        ShadeProf sprof;
+#endif
+        const bool ended = shade_surface<double, kProbeFeat, kMat>(L, sf, sc, sc.materials, cnt RTK_SHADE_PROF_ARG);
         L.kind = ended ? 1u : 0u;
     } else if constexpr (KIND == PROBE_PARTIAL) {
         store_partial(partial, int(L.segs), L.depth, L.sum);

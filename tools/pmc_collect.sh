@@ -5,7 +5,7 @@
 # with --kernel-trace/--stats; the program goes directly after `--` (no env/bash hop under rocprofv3).
 #   tools/pmc_collect.sh <config> [round=r02] [steps=2]
 set -e
-cfg=$1; round=${2:-r02}; steps=${3:-2}
+cfg=$1; round=${2:-r03}; steps=${3:-2}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/pmc_${round}_${cfg}
 rm -rf "$out"; mkdir -p "$out" profiles

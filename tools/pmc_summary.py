@@ -77,6 +77,13 @@ for f in newest_per_pass(os.path.join(out, "stats", "**", "*kernel_trace.csv")):
 for f in newest_per_pass(os.path.join(out, "stats", "**", "*kernel_stats.csv")):
     shutil.copy(f, os.path.join(ROOT, "profiles", f"{rnd}_kernel_stats_{cfg}.csv"))
 kernel_ms_profiled = sum(dur) / len(dur) if dur else None
+# A frame with more than 21 sample chunks is SEVERAL launches of the timed kernel (passes over the chunks, csrc/rtk_api.cpp):
+# bench.py's kernel_ms brackets the frame, so the additive counters and the duration are scaled from "mean dispatch" to "frame".
+launches = int(line["roofline"].get("launches_per_frame") or 1)
+if launches > 1:
+    vals = {k: v * launches for k, v in vals.items()}
+    if kernel_ms_profiled is not None:
+        kernel_ms_profiled *= launches
 
 import bench  # noqa: E402  (kernel_source_hash)
 
@@ -89,7 +96,8 @@ rec = {
     "order": line["config"]["order"], "source_hash": source_hash,
     "method": "rocprofv3 --pmc passes over `python3 bench.py --config %s ...` (tools/pmc_collect.sh), mean over the dispatches of the timed kernel; "
               "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B); durations from a separate --kernel-trace --stats run" % cfg,
-    "counters": vals, "dispatches_averaged": n_disp, "kernel_ms_profiled": kernel_ms_profiled, "kernel_ms_bench_events": line["roofline"]["kernel_ms"],
+    "counters": vals, "dispatches_averaged": n_disp, "launches_per_frame": launches,
+    "counters_are": "per frame = mean over the timed kernel's dispatches x launches_per_frame", "kernel_ms_profiled": kernel_ms_profiled, "kernel_ms_bench_events": line["roofline"]["kernel_ms"],
     "vgpr": meta.get("VGPR_Count"), "sgpr": meta.get("SGPR_Count"), "scratch": meta.get("Scratch_Size"), "lds_block": meta.get("LDS_Block_Size"),
     "workgroup": meta.get("Workgroup_Size"), "grid": meta.get("Grid_Size"),
 }

@@ -60,6 +60,7 @@ Extra objects on the JSON line:
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import subprocess
@@ -612,7 +613,7 @@ def main():
         roofline = {"bound": "valu", "achieved": None, "peak": round(N_SIMDS * MAX_CLOCK_GHZ, 1), "unit": "G VALU pipe-cycles/s", "frac": None, "traffic": None,
                     "kernel": kernel, "kernel_ms": round(kernel_ms, 4),
                     # a frame with more than 21 sample chunks (spp > 168) is several launches of the kernel; kernel_ms and every counter are per FRAME
-                    "launches_per_frame": rt.hip_lib().rtk_frame_launches(spp, args.variant)}
+                    "launches_per_frame": rt.hip_lib().rtk_frame_launches(ctypes.byref(cam), ctypes.byref(rt.RenderOpts(rt.RENDER_SEED, rt.RTK_REAL_F64, rank, n, 0, args.variant, None)))}
         # measured ceilings of THIS box (csrc/rtk_microbench.hip): achievable HBM rate from a stream copy, the LDS
         # read rate the byte model is served at, and the issue cost of each VALU class the roofline prices
         measured, measured_why = None, None

@@ -214,7 +214,7 @@ typedef struct rtk_render_opts {
                              * buffer [tiles][3][64] also when n_ranks == 1 (rtk_multi's one-device RCCL path; d_rgb8 NULL);
                              * bit 23 = the hot/cold form of a COMPACT program (quads and triangles in memory, the rest in
                              * LDS) although the whole program would fit (tests); bit 24 = render every sample chunk in ONE
-                             * launch with a partial-sum plane per chunk (up to 64) instead of passes of 21 chunks whose running
+                             * launch with a partial-sum plane per chunk (up to 64) instead of passes over as many chunks as the 1.1 GB workspace budget holds planes for, whose running
                              * sum the resolve kernel carries (tests: the same additions in the same order, the same image) */
     void* stream;           /* hipStream_t, NULL = default stream */
 } rtk_render_opts;
@@ -465,10 +465,12 @@ int rtk_debug_get_ray(rtk_ctx* ctx, int real_mode, const rtk_camera* cam, uint32
  * for the byte model): number of program slots (fused records) and device bytes per mode. */
 int rtk_scene_info(rtk_ctx* ctx, int32_t* n_program_ops, int64_t* bytes_f64, int64_t* bytes_f32);
 
-/* Render-kernel launches one frame takes (host-only): a pixel's samples are split into chunks of 8 (at most 64 chunks),
- * and a frame with more than 21 chunks is rendered in consecutive passes over the chunks whose running sums the resolve
- * kernel carries -- the image is the same for any number of passes.  1 up to 168 samples per pixel, 3 at 1000. */
-int rtk_frame_launches(int samples_per_pixel, int variant);
+/* Render-kernel launches one frame takes (host-only): a pixel's samples are split into chunks of 8 (at most 64 chunks); the
+ * partial-sum workspace is budgeted at 1.095 GB per context (22 planes of a 1920x1080 f64 frame), and a frame with more
+ * chunks than the budget holds planes for is rendered in consecutive passes over the chunks whose running sums the resolve
+ * kernel carries -- the image is the same for any number of passes.  1920x1080 f64: 1 launch up to 168 samples per pixel,
+ * 3 at 1000; 800x800, or an eighth of the 1920x1080 tiles: 1 at 1000.  (opts: real_mode, rank / n_ranks, variant.) */
+int rtk_frame_launches(const rtk_camera* cam, const rtk_render_opts* opts);
 
 /* Names of the kernel symbols rtk_render_device launches for (real_mode,
  * variant) on the uploaded scene -- used to find the dispatch in rocprofv3

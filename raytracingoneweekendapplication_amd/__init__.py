@@ -195,7 +195,7 @@ def hip_lib() -> C.CDLL:
         lib.rtk_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.rtk_debug_closest_hit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         try:
-            lib.rtk_frame_launches.argtypes = [C.c_int, C.c_int]
+            lib.rtk_frame_launches.argtypes = [C.POINTER(Camera), C.POINTER(RenderOpts)]
             lib.rtk_debug_scatter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
             lib.rtk_debug_texture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
             lib.rtk_debug_get_ray.argtypes = [C.c_void_p, C.c_int, C.POINTER(Camera), C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]

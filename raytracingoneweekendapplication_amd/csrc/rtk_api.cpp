@@ -948,22 +948,34 @@ struct rtk_ctx {
     void* progress_user = nullptr;
     int progress_interval_ms = 100;
     // a frame is up to kMaxPasses launches (one per range of sample chunks): the work-item counter of each and what it hands out
-    const unsigned int* last_tile_counter[4] = {nullptr, nullptr, nullptr, nullptr};
-    int64_t last_pass_items[4] = {0, 0, 0, 0};
+    const unsigned int* last_tile_counter[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int64_t last_pass_items[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int last_n_passes = 0;
     int64_t last_n_items = 0;               // of the whole frame
     hipStream_t progress_stream = nullptr;
     unsigned int* progress_word = nullptr;  // pinned host memory, one word per pass
     bool progress_pending = false;
 };
-// Sample chunks per launch: the partial-sum workspace holds this many planes [local tile][3][64] (+ one for the running sum
-// of a frame that needs several launches).  1920x1080 in f64: 21 + 1 planes = 1.09 GB, where the 63 chunks of a 1000-spp
+// Sample chunks per launch: the partial-sum workspace holds up to this many planes [local tile][3][64] at 1920x1080 f64 (+ one
+// for the running sum of a frame that needs several launches): 21 + 1 planes = 1.09 GB, where the 63 chunks of a 1000-spp
 // frame used to take 3.14 GB per context.  Every launch has a fixed cost -- staging the program, the drain of its last long
 // paths -- measured on the full-size frames (same box, same image): one launch / passes of 16 chunks: C5 999.6 / 1014.6 ms,
 // C3 247.7 / 254.5 ms; 21 chunks per pass makes a 1000-spp frame three launches instead of four.  Frames of up to 168 spp
 // (C2: 13 chunks) are one launch as before.
 constexpr int kMaxPlanesPerPass = 21;
-constexpr int kMaxPasses = (rtk::kMaxChunks + kMaxPlanesPerPass - 1) / kMaxPlanesPerPass;
+// The plane count is a BUDGET, not a constant: 22 planes of a 1920x1080 f64 frame = 1.095 GB per context.  A smaller
+// frame -- 800x800, or one rank's share of the tiles on several GPUs -- gets as many planes as that budget holds (up to all
+// 64 chunks: the Cornell box at 1000 spp is one launch again, 247.7 instead of 251.8 ms), a larger one at least 8.
+constexpr size_t kWorkspaceBudgetBytes = size_t(22) * 32400 * 192 * 8;
+constexpr int kMinPlanesPerPass = 8;
+constexpr int kMaxPasses = (rtk::kMaxChunks + kMinPlanesPerPass - 1) / kMinPlanesPerPass;
+static int planes_per_pass_for(size_t plane_bytes, int variant) {
+    if (variant & (1 << 24)) return rtk::kMaxChunks;  // variant bit 24: one pass whatever the chunk count (tests: same image)
+    if (plane_bytes == 0) return rtk::kMaxChunks;
+    const size_t fit = kWorkspaceBudgetBytes / plane_bytes;  // planes the budget holds, one of them the running sum
+    const int planes = fit > size_t(rtk::kMaxChunks) ? rtk::kMaxChunks : (fit < size_t(kMinPlanesPerPass + 1) ? kMinPlanesPerPass : int(fit) - 1);
+    return planes;
+}
 // Samples per chunk: 8, or the smallest size that keeps a pixel's chunks within kMaxChunks -- a function of spp only.
 static int chunk_size_for(int spp, int variant) {
     const int ab = (variant >> 3) & 3;  // tools/: chunk size A/B (0 = default 8, 1 = 4, 2 = 2, 3 = 16)
@@ -972,7 +984,7 @@ static int chunk_size_for(int spp, int variant) {
     while ((spp + size - 1) / size > rtk::kMaxChunks) size++;
     return size;
 }
-static_assert(kMaxPasses <= 4, "rtk_ctx keeps four pass counters");
+static_assert(kMaxPasses <= 8, "rtk_ctx keeps eight pass counters");
 constexpr unsigned int kCounterRing = 256;
 constexpr size_t kCameraStride = 256;
 static_assert(sizeof(CameraRec<double>) <= kCameraStride, "camera stride");
@@ -1004,7 +1016,7 @@ int wait_with_progress(rtk_ctx* const* ctxs, const hipStream_t* streams, int n) 
         if (!c->progress_stream) {
             (void)hipSetDevice(c->device);
             if (hipStreamCreateWithFlags(&c->progress_stream, hipStreamNonBlocking) != hipSuccess) c->progress_stream = nullptr;
-            if (hipHostMalloc(reinterpret_cast<void**>(&c->progress_word), 4 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) c->progress_word = nullptr;
+            if (hipHostMalloc(reinterpret_cast<void**>(&c->progress_word), 8 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) c->progress_word = nullptr;
         }
         c->progress_pending = false;
     }
@@ -1289,9 +1301,9 @@ int rtk_render_device(rtk_ctx* ctx, const rtk_camera* cam, const rtk_render_opts
     // Up to kMaxPlanesPerPass chunks per launch; a frame with more is rendered in consecutive passes, the resolve kernel
     // carrying the running sum in one extra plane -- the same additions in the same order as one pass over all chunks.
     const int n_chunks_total = tm.n_chunks;
-    const int planes_per_pass = (opts->variant & (1 << 24)) ? kMaxChunks : kMaxPlanesPerPass;  // variant bit 24: one pass whatever the chunk count (tests: same image)
-    const int n_passes = (n_chunks_total + planes_per_pass - 1) / planes_per_pass;
     const size_t plane = size_t(tm.n_tiles_local) * 192 * elem;
+    const int planes_per_pass = planes_per_pass_for(plane, opts->variant);
+    const int n_passes = (n_chunks_total + planes_per_pass - 1) / planes_per_pass;
     const size_t need = plane * size_t(n_passes > 1 ? planes_per_pass + 1 : n_chunks_total);
     if (need > ctx->partial_bytes) {
         if (ctx->d_partial) {
@@ -1559,11 +1571,14 @@ int rtk_debug_get_ray(rtk_ctx* ctx, int real_mode, const rtk_camera* cam, uint32
     return RTK_OK;
 }
 
-int rtk_frame_launches(int samples_per_pixel, int variant) {
-    if (samples_per_pixel <= 0 || samples_per_pixel > 32767) return fail(RTK_ERR_INVALID, "rtk_frame_launches: samples_per_pixel must be 1..32767");
-    const int size = chunk_size_for(samples_per_pixel, variant);
-    const int chunks = (samples_per_pixel + size - 1) / size;
-    const int per_pass = (variant & (1 << 24)) ? rtk::kMaxChunks : kMaxPlanesPerPass;
+int rtk_frame_launches(const rtk_camera* cam, const rtk_render_opts* opts) {
+    if (!cam || !opts || cam->samples_per_pixel <= 0 || cam->samples_per_pixel > 32767 || cam->image_width <= 0 || cam->image_height <= 0 || opts->n_ranks < 1)
+        return fail(RTK_ERR_INVALID, "rtk_frame_launches: bad camera or options");
+    const int size = chunk_size_for(cam->samples_per_pixel, opts->variant);
+    const int chunks = (cam->samples_per_pixel + size - 1) / size;
+    const size_t elem = opts->real_mode == RTK_REAL_F64 ? sizeof(double) : sizeof(float);
+    const size_t plane = size_t(rtk_tiles_per_rank(cam->image_width, cam->image_height, opts->n_ranks)) * 192 * elem;
+    const int per_pass = planes_per_pass_for(plane, opts->variant);
     return (chunks + per_pass - 1) / per_pass;
 }
 

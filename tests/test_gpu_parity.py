@@ -331,37 +331,68 @@ def test_config4_and_config5_full_resolution_reduced_spp_properties(rt, orc, ren
 
 
 def test_frames_with_many_sample_chunks_are_rendered_in_passes_with_the_same_sums(rt, orc, renderer, scenes):
-    """More than 21 sample chunks (spp > 168): the frame is rendered in passes of 21 chunks, the resolve kernel carrying every
-    pixel's running sum from pass to pass, so that the partial-sum workspace stays at 22 planes (1000 spp used to take 63).
-    The additions are those of one pass over all chunks, in the same order: the image must be the one-launch image (variant
-    bit 24) bit for bit -- whole, sharded over ranks, in float -- and the oracle's within rounding; progress reports of a
-    blocking render add the passes up monotonically."""
-    scene = scenes("book1_final")
-    cam = scene.camera(96, 54, 8 * 47, 12)           # 47 chunks of 8 samples: passes of 21 + 21 + 5
-    renderer.upload_fast(scene, cam.center)
-    seen = []
-    renderer.set_progress(lambda done, total: seen.append((done, total)), interval_ms=1)
-    passes, passes8, _ = renderer.render_host(cam)
-    renderer.set_progress(None)
-    one, one8, _ = renderer.render_host(cam, variant=1 << 24)
-    assert np.array_equal(passes, one) and np.array_equal(passes8, one8)
-    n_items = -(-96 // 8) * -(-54 // 8) * 47
-    assert seen and seen[-1] == (n_items, n_items) and all(0 <= a[0] <= b[0] <= b[1] for a, b in zip(seen, seen[1:]))
-    ref, ref8, _ = orc.render(scene.desc_ptr, cam, RENDER_SEED, 8)
-    assert np.sqrt(np.mean((passes - ref) ** 2)) < 1e-12 and np.array_equal(passes8, ref8)
-    f32_passes, _, _ = renderer.render_host(cam, real_mode=rt.RTK_REAL_F32)
-    f32_one, _, _ = renderer.render_host(cam, real_mode=rt.RTK_REAL_F32, variant=1 << 24)
-    assert np.array_equal(f32_passes, f32_one)
+    """More sample chunks than the partial-sum workspace (budget: 1.095 GB per context = 22 planes of a 1920x1080 f64 frame) holds
+    planes for: the frame is rendered in passes over the chunks, the resolve kernel carrying every pixel's running sum from
+    pass to pass (1000 spp at 1920x1080 used to take 63 planes, 3.1 GB).  The additions are those of one pass over all chunks,
+    in the same order: the image must be the one-launch image (variant bit 24) bit for bit -- whole and sharded over ranks
+    (a rank's share fits the budget: one launch) -- and the oracle's on probed pixels; progress reports of a blocking render
+    add the passes up monotonically.  A frame of 1024x704 with 64 chunks of 2 samples (variant bits 3-4) is 1.107 GB of
+    planes: 62 + 2."""
+    import ctypes as C
+
     import torch
+
+    scene = scenes("book1_final")
+    W, H, spp = 1024, 704, 128
+    cam = scene.camera(W, H, spp, 6)
+    CH2 = 2 << 3                                     # chunks of 2 samples: 64 chunks
+    opts = rt.RenderOpts(RENDER_SEED, rt.RTK_REAL_F64, 0, 1, 0, CH2, None)
+    assert rt.hip_lib().rtk_frame_launches(C.byref(cam), C.byref(opts)) == 2
+    opts.variant = CH2 | (1 << 24)
+    assert rt.hip_lib().rtk_frame_launches(C.byref(cam), C.byref(opts)) == 1
+    opts.variant, opts.n_ranks = CH2, 3
+    assert rt.hip_lib().rtk_frame_launches(C.byref(cam), C.byref(opts)) == 1           # a third of the tiles: everything fits
+    full = scene.camera(1920, 1080, 1000, 10)
+    opts = rt.RenderOpts(RENDER_SEED, rt.RTK_REAL_F64, 0, 1, 0, 0, None)
+    assert rt.hip_lib().rtk_frame_launches(C.byref(full), C.byref(opts)) == 3          # C5's size: 21 + 21 + 21 of 63 chunks
+    opts.n_ranks = 8
+    assert rt.hip_lib().rtk_frame_launches(C.byref(full), C.byref(opts)) == 1          # ... and one launch on an eighth of it
+    renderer.upload_fast(scene, cam.center)
     dev = torch.device("cuda", 0)
-    tpr = rt.tiles_per_rank(96, 54, 3)
+    image = torch.zeros((H, W, 3), dtype=torch.float64, device=dev)
+    bytes8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+    renderer.render_device(cam, image.data_ptr(), bytes8.data_ptr(), variant=CH2)
+    torch.cuda.synchronize()
+    passes, passes8 = image.cpu().numpy().copy(), bytes8.cpu().numpy().copy()
+    renderer.render_device(cam, image.data_ptr(), bytes8.data_ptr(), variant=CH2 | (1 << 24))
+    torch.cuda.synchronize()
+    assert np.array_equal(image.cpu().numpy(), passes) and np.array_equal(bytes8.cpu().numpy(), passes8)
+    rng = np.random.default_rng(5)
+    rgb = (C.c_double * 3)()
+    for _ in range(12):                              # the oracle's per-sample values of random pixels, summed in chunk order
+        i, j = int(rng.integers(0, W)), int(rng.integers(0, H))
+        total = np.zeros(3)
+        for c0 in range(0, spp, 2):
+            part = np.zeros(3)
+            for s_ in range(c0, c0 + 2):
+                orc.lib().orc_sample(scene.desc_ptr, C.addressof(cam), RENDER_SEED, i, j, s_, C.addressof(rgb), None)
+                part = part + np.array(rgb[:])
+            total = part if c0 == 0 else total + part
+        assert np.abs(total * cam.pixel_samples_scale - passes[j, i]).max() < 1e-12, (i, j)   # (the oracle multiplies attenuations recursively, the kernel iteratively: ~1e-17)
+    tpr = rt.tiles_per_rank(W, H, 3)
     gathered = torch.zeros((3, tpr, 3, 64), dtype=torch.float64, device=dev)
     for rank in range(3):
-        renderer.render_device(cam, gathered[rank].data_ptr(), 0, rank=rank, n_ranks=3)
-    image = torch.zeros((54, 96, 3), dtype=torch.float64, device=dev)
-    renderer.unpermute(96, 54, 3, rt.RTK_REAL_F64, gathered.data_ptr(), image.data_ptr(), 0)
+        renderer.render_device(cam, gathered[rank].data_ptr(), 0, rank=rank, n_ranks=3, variant=CH2)
+    renderer.unpermute(W, H, 3, rt.RTK_REAL_F64, gathered.data_ptr(), image.data_ptr(), 0)
     torch.cuda.synchronize()
     assert np.array_equal(image.cpu().numpy(), passes)
+    small = scene.camera(128, 64, 16, 6)             # a blocking render of a small frame forced into passes: progress adds them up
+    seen = []
+    renderer.set_progress(lambda done, total: seen.append((done, total)), interval_ms=1)
+    a_img, a8, _ = renderer.render_host(small, variant=CH2)
+    renderer.set_progress(None)
+    n_items = (128 // 8) * (64 // 8) * 8
+    assert seen and seen[-1] == (n_items, n_items) and all(0 <= a[0] <= b[0] <= b[1] for a, b in zip(seen, seen[1:]))
 
 
 FULL_SIZE_CONFIGS = [

@@ -264,7 +264,7 @@ def parse_args():
                         "process after its own measurement (--no-abi-path skips it) and reports it under multi_paths")
     p.add_argument("--multi-devices", default="", help="--multi abi: comma-separated HIP ordinals (default 0..N-1); an ordinal may repeat (one-GPU rehearsal)")
     p.add_argument("--no-abi-path", action="store_true")
-    p.add_argument("--abi-timeout", type=float, default=240.0)
+    p.add_argument("--abi-timeout", type=float, default=150.0)
     p.add_argument("--rehearse-one-gpu", action="store_true",
                    help="dev only: run all ranks on device 0 with a gloo gather through host memory, to rehearse the N>1 control flow on a 1-GPU box")
     return p.parse_args()

@@ -22,7 +22,8 @@ r = rt.Renderer(0)
 fast = scene.fast_order(cam.center)
 use_fast = order == "fast" or (order == "auto" and fast.exact)  # same rule as bench.py
 prim_cost, free_media = float(os.environ.get("AB_PRIM_COST", "0")), os.environ.get("AB_FREE_MEDIA", "0") == "1"   # sweeps of the optimiser's knobs
-r.upload_fast(scene, cam.center, prim_cost_scale=prim_cost, free_media_order=free_media) if use_fast else r.upload(scene)
+max_leaf = int(os.environ.get("AB_MAX_LEAF", "0"))
+r.upload_fast(scene, cam.center, max_leaf=max_leaf, prim_cost_scale=prim_cost, free_media_order=free_media) if use_fast else r.upload(scene)
 print(f"order: {'fast (rtk_scene_upload_fast)' if use_fast else 'reference (bvh.h)'}", flush=True)
 dev = torch.device("cuda", 0)
 H, W = cam.image_height, cam.image_width

@@ -277,8 +277,14 @@ int rtk_render_multi_enqueue(rtk_multi* m, const rtk_camera* cam, const rtk_rend
     int32_t plan[2];
     (void)rtk_multi_frame_plan(int64_t(m->frames_enqueued), plan);
     const int slot = plan[0];
+    // a buffer of this set has to grow (first use, or a larger frame): nothing may still be reading or filling the old one --
+    // peer copies and gathers of frames in flight run on OTHER devices' streams, which a device-local synchronise does not see
+    bool must_grow = part * size_t(n) > m->gathered_bytes[slot];
+    for (int i = 1; i < n; i++) must_grow = must_grow || part > m->compact_bytes[slot][size_t(i)];
+    int rc = RTK_OK;
+    if (must_grow && m->frames_enqueued > 0 && (rc = rtk_multi_wait(m)) != RTK_OK) return rc;
     RTKM_HIP(hipSetDevice(m->devices[0]));
-    int rc = grow(&m->gathered[slot], &m->gathered_bytes[slot], part * size_t(n));
+    rc = grow(&m->gathered[slot], &m->gathered_bytes[slot], part * size_t(n));
     if (rc != RTK_OK) return rc;
     for (int i = 1; i < n; i++) {
         RTKM_HIP(hipSetDevice(m->devices[size_t(i)]));

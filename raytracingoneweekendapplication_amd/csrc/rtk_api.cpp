@@ -64,6 +64,7 @@ struct ChainStep {
 using Chain = std::vector<ChainStep>;
 
 struct Program {
+    bool has_media_bracket = false;  // a constant_medium whose boundary is not one stationary sphere: OP_MED_BEGIN / MID / END records
     std::vector<Op> ops;
     std::vector<uint32_t> ranks;  // parallel to ops: rtk_node.c of a primitive op (1 + reference visiting rank; 0 = none)
     std::vector<uint32_t> extra;  // parallel to ops: OP_MED_SPHERE -> index of the boundary sphere
@@ -183,6 +184,7 @@ struct Compiler {
                         return true;
                     }
                 }
+                prog.has_media_bracket = true;
                 push(OP_MED_BEGIN, uint32_t(n.a), 0);
                 if (!emit(n.b, chain, true, depth + 1)) return false;
                 uint32_t mid = push(OP_MED_MID, uint32_t(n.a), 0);
@@ -1238,6 +1240,9 @@ static int upload_scene(rtk_ctx* ctx, const rtk_scene_desc* scene, UploadOrder o
     for (int32_t i = 0; i < scene->n_materials; i++)
         if (scene->materials[i].kind != RTK_MAT_LAMBERTIAN && scene->materials[i].kind != RTK_MAT_DIFFUSE_LIGHT) matte = false;
     if (matte) hierarchy_flags |= F_MATTE;
+#ifndef RTK_NO_SPHERE_MEDIA_ONLY   // (A/B builds)
+    if ((prog.features & F_MEDIA) != 0 && !prog.has_media_bracket) hierarchy_flags |= F_SPHERE_MEDIA_ONLY;
+#endif
 
     RTK_HIP(hipSetDevice(ctx->device));
     ctx->has_scene = false;

@@ -186,7 +186,11 @@ enum Feature : uint32_t {
     F_MATTE = 1u << 9,
     // Not a scene feature either: the program is too large for LDS but its box records are not -- the kernel stages the
     // boxes alone (SceneView::box_cache), the per-slot kind nibbles and a rank table in LDS; primitives stay in HBM/L2.
-    F_LDS_BOXES = 1u << 10
+    F_LDS_BOXES = 1u << 10,
+    // A restriction like F_MATTE: every constant_medium of the scene is bounded by one stationary sphere (OP_MED_SPHERE records
+    // only: book 2).  The full-feature kernel then carries neither the OP_MED_BEGIN / MID / END steps nor the parked outer
+    // query they need (sv_tmin, sv_best_t, rec1_t, sv_best_pc): 168 VGPRs + 96 B of scratch instead of + 160 B at three waves.
+    F_SPHERE_MEDIA_ONLY = 1u << 11
 };
 constexpr uint32_t kFeatLean = 0;                       // spheres + lambertian/metal/dielectric with solid colours
 constexpr uint32_t kFeatAll = 0x7F;

@@ -282,7 +282,13 @@ int rtk_render_multi_enqueue(rtk_multi* m, const rtk_camera* cam, const rtk_rend
     bool must_grow = part * size_t(n) > m->gathered_bytes[slot];
     for (int i = 1; i < n; i++) must_grow = must_grow || part > m->compact_bytes[slot][size_t(i)];
     int rc = RTK_OK;
-    if (must_grow && m->frames_enqueued > 0 && (rc = rtk_multi_wait(m)) != RTK_OK) return rc;
+    if (must_grow && m->frames_enqueued > 0) {  // (plain synchronisation: no progress callback for frames that are not this call's)
+        for (int i = 0; i < n; i++) {
+            RTKM_HIP(hipSetDevice(m->devices[size_t(i)]));
+            RTKM_HIP(hipStreamSynchronize(m->streams[size_t(i)]));
+            RTKM_HIP(hipStreamSynchronize(m->xfer[size_t(i)]));
+        }
+    }
     RTKM_HIP(hipSetDevice(m->devices[0]));
     rc = grow(&m->gathered[slot], &m->gathered_bytes[slot], part * size_t(n));
     if (rc != RTK_OK) return rc;

@@ -853,7 +853,7 @@ RTK_DEV bool compact_ch_records(const SceneView<real>& sc) {
 // Every other record kind (moving sphere, quad, triangle, chain switch, the three medium ops, a box met by a ray the
 // box loop does not take).  `rec` points at the record in the program (LDS or global), in the slot layout (Slot<real>)
 // or -- F_F32_BOX kernels of the non-lean families -- the COMPACT one (Unit16).
-template <typename real, uint32_t FEAT, bool COUNT, typename Rec, typename Tie>
+template <typename real, uint32_t FEAT, bool BRACKET = true, bool COUNT, typename Rec, typename Tie>
 RTK_DEV void step_other(Lane<real>& L, const Rec* __restrict__ rec, const SceneView<real>& sc, Counters<COUNT>& cnt, const Tie& tie, float extent = 0.0f) {
     constexpr bool XF = (FEAT & F_XFORM) != 0;
     constexpr bool MIXED = (FEAT & F_F32_BOX) != 0;  // here: the COMPACT program (f32 culling boxes; the float interval follows every change)
@@ -908,7 +908,7 @@ RTK_DEV void step_other(Lane<real>& L, const Rec* __restrict__ rec, const SceneV
             }
         }
         L.pc += rec_units<real>(rec, kind);
-    } else if ((FEAT & F_MEDIA) && kind == OP_MED_BEGIN) {
+    } else if ((FEAT & F_MEDIA) && BRACKET && kind == OP_MED_BEGIN) {
         cnt.inc(C_MEDIUM);
         L.sv_tmin = L.tmin;
         L.sv_best_t = L.best_t;
@@ -918,7 +918,7 @@ RTK_DEV void step_other(Lane<real>& L, const Rec* __restrict__ rec, const SceneV
         L.best_pc = kNoHit;
         L.pc += rec_units<real>(rec, kind);
         if constexpr (MIXED) sync_interval32(L);
-    } else if ((FEAT & F_MEDIA) && kind == OP_MED_MID) {
+    } else if ((FEAT & F_MEDIA) && BRACKET && kind == OP_MED_MID) {
         if (L.best_pc == kNoHit) {  // constant_medium.h:23-24
             L.tmin = L.sv_tmin;
             L.best_t = L.sv_best_t;
@@ -932,7 +932,7 @@ RTK_DEV void step_other(Lane<real>& L, const Rec* __restrict__ rec, const SceneV
             L.pc += rec_units<real>(rec, kind);
         }
         if constexpr (MIXED) sync_interval32(L);
-    } else if ((FEAT & F_MEDIA) && kind == OP_MED_END) {
+    } else if ((FEAT & F_MEDIA) && BRACKET && kind == OP_MED_END) {
         const bool hit2 = L.best_pc != kNoHit;
         real r2 = L.best_t;
         L.tmin = L.sv_tmin;
@@ -1535,7 +1535,7 @@ RTK_DEV void store_partial(real* __restrict__ partial, int item, int pix, V3<rea
 // memory: 23.2 ms at three waves, 33.6 at four), so those keep 768 threads.
 template <typename real>
 constexpr int max_threads_of(uint32_t feat, bool in_lds) {
-    const uint32_t scene_feat = feat & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE | F_LDS_BOXES);
+    const uint32_t scene_feat = feat & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE | F_LDS_BOXES | F_SPHERE_MEDIA_ONLY);
     // ... and the full-feature f64 kernels run at three waves where the traversal data is in LDS -- the whole program, or the
     // hot part of a COMPACT program (F_LDS_BOXES | F_F32_BOX: C5 at 16 spp 21.1 -> 17.7 ms) -- and stay at two where records
     // come from memory (program in global memory 25.5 vs 29.1 ms at three; slot program with its boxes in LDS 25.6 vs 29.0).
@@ -1567,7 +1567,8 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL, IN_LDS>())) void rtk_r
 #ifndef RTK_DEV_MASK_OFF
 #define RTK_DEV_MASK_OFF 0u   // register-pressure experiments (tools/kernel_resources.py): feature bits compiled out of every kernel
 #endif
-    constexpr uint32_t FEAT = FEAT_ALL & ~uint32_t(F_LDS_BOXES) & ~uint32_t(RTK_DEV_MASK_OFF);
+    constexpr uint32_t FEAT = FEAT_ALL & ~uint32_t(F_LDS_BOXES | F_SPHERE_MEDIA_ONLY) & ~uint32_t(RTK_DEV_MASK_OFF);
+    constexpr bool BRACKET = (FEAT_ALL & F_SPHERE_MEDIA_ONLY) == 0;  // generic media (OP_MED_BEGIN / MID / END) may occur in the program
     constexpr bool LDS_PART = (FEAT_ALL & F_LDS_BOXES) != 0;  // a program larger than LDS, part of it staged there
     static_assert(!LDS_PART || !IN_LDS, "F_LDS_BOXES: for programs that do not fit LDS");
     constexpr bool MIXED = (FEAT & F_F32_BOX) != 0;  // f32 culling boxes + exact primitives (f64 kernels, fast order): ...
@@ -2256,7 +2257,7 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL, IN_LDS>())) void rtk_r
             // counters, C5 42.9 vs 41.9 ms at 32 spp.)
             if (m_oth >> lane & 1ull) {
                 if constexpr (MIXED && !COMPACT) step_other_mixed<kPcUnit>(L, rec_at(L.pc), cnt, tie, extent);
-                else step_other<real, FEAT, COUNT>(L, prog + L.pc, sc, cnt, tie, extent);
+                else step_other<real, FEAT, BRACKET>(L, prog + L.pc, sc, cnt, tie, extent);
                 L.kind = kind_of(L.pc);
             }
             RTK_PROF_MARK(4, 1, n_oth)
@@ -2307,7 +2308,7 @@ __global__ __launch_bounds__(256) void rtk_debug_hit_kernel(SceneView<real> sc, 
         } else if (kind == OP_SPHERE) {
             step_sphere<true>(L, *rec, cnt, tie);
         } else {
-            step_other<real, kFeatAll, true>(L, rec, sc, cnt, tie);
+            step_other<real, kFeatAll>(L, rec, sc, cnt, tie);
         }
     }
     double* o = out + size_t(gid) * 12;
@@ -2666,7 +2667,14 @@ static bool use_compact_program(const SceneView<real>& sc, uint32_t diag) {
 
 // Kernel instantiation for a scene: the leanest feature subset that covers it, with or without the fused slab test;
 // `mixed` / `compact` = the scene has that program and the caller did not ask for the f64 boxes.
+static uint32_t kernel_features_base(uint32_t features, bool count, bool mixed, bool compact);
 static uint32_t kernel_features(uint32_t features, bool count, bool mixed, bool compact) {
+    const uint32_t sphere_media = count ? 0u : (features & F_SPHERE_MEDIA_ONLY);  // (the counting kernels serve every scene: no restriction)
+    features &= ~uint32_t(F_SPHERE_MEDIA_ONLY);
+    const uint32_t base = kernel_features_base(features, count, mixed, compact);
+    return base == (kFeatAll | uint32_t(F_F32_BOX)) ? (base | sphere_media) : base;  // the COMPACT full-feature kernels (what bench.py times on C5) have the restricted variant
+}
+static uint32_t kernel_features_base(uint32_t features, bool count, bool mixed, bool compact) {
     const uint32_t fma = features & F_FMA_BOX, matte = features & F_MATTE, scene = features & ~uint32_t(F_FMA_BOX | F_MATTE);
     const uint32_t f32box = uint32_t(F_F32_BOX);
     // counting instantiations: the MIXED program has its own (the kernel bench.py times on sphere-only scenes, with
@@ -2698,7 +2706,7 @@ static KernelChoice choose_kernel(const SceneView<real>& sc, uint32_t features, 
         if (!(allow_lds && bytes <= size_t(kLdsBytesPerCU)) || (diag & (1u << 23)) != 0) {  // (variant bit 23: the hot/cold form although the whole would fit)
             // ... unless its hot part does (COLD kernels: quads and triangles stay in memory, everything else in LDS) -- full-feature family, timed kernels
             const size_t hot = size_t(sc.n_hot_units) * sizeof(Unit16) + size_t(sc.n_materials) * sizeof(MaterialRec<real>);
-            const uint32_t scene = features & ~uint32_t(F_FMA_BOX | F_MATTE);
+            const uint32_t scene = features & ~uint32_t(F_FMA_BOX | F_MATTE | F_SPHERE_MEDIA_ONLY);
             cold = allow_lds && !count && sc.program_hot != nullptr && hot + 64 <= size_t(kLdsBytesPerCU) && (diag & (1u << 21)) == 0 &&
                    (scene & ~kFeatQuadBox) != 0 && (scene & ~kFeatMesh) != 0;
             compact = cold;
@@ -2706,13 +2714,14 @@ static KernelChoice choose_kernel(const SceneView<real>& sc, uint32_t features, 
     }
     // the matte variants pay off in f64 only (C3: f64 34.8 -> 31.9 ms, f32 26.6 -> 36.5 ms at one more wave per SIMD)
     KernelChoice k{kernel_features(sizeof(real) == 8 ? features : (features & ~uint32_t(F_MATTE)), count, mixed, compact), count, false};
-    const uint32_t scene = k.feat & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE);
+    const uint32_t scene = k.feat & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE | F_SPHERE_MEDIA_ONLY);
     const bool fits = allow_lds && lds_image_bytes(sc, k.feat) <= size_t(kLdsBytesPerCU);
     if (count) {  // counting builds: only the MIXED one stages its program (it is the timed kernel with counters)
         k.in_lds = fits && (k.feat & F_F32_BOX) != 0 && !is_compact(k.feat);
         return k;
     }
     k.in_lds = fits;
+    if (!fits && !cold) k.feat &= ~uint32_t(F_SPHERE_MEDIA_ONLY);  // (the restricted variant exists for the LDS-resident forms only)
     if (cold) {
         k.in_lds = false;
         k.feat |= uint32_t(F_LDS_BOXES);
@@ -2739,7 +2748,12 @@ static hipError_t launch_feat(const KernelChoice& k, const SceneView<real>& sc, 
     }
     if constexpr (FEAT == (kFeatAll | uint32_t(F_F32_BOX))) {  // work counters on the COMPACT program (any family's scene)
         if (k.count) RTK_GO(FEAT, true, false);
-        if (k.feat & F_LDS_BOXES) RTK_GO(FEAT | uint32_t(F_LDS_BOXES), false, false);  // COLD: hot program in LDS, quads / triangles in memory
+        constexpr uint32_t SMO = uint32_t(F_SPHERE_MEDIA_ONLY);  // every medium of the scene is sphere-bounded: the variant without the generic bracket
+        if (k.feat & F_LDS_BOXES) {  // COLD: hot program in LDS, quads / triangles in memory
+            if (k.feat & SMO) RTK_GO(FEAT | uint32_t(F_LDS_BOXES) | SMO, false, false);
+            RTK_GO(FEAT | uint32_t(F_LDS_BOXES), false, false);
+        }
+        if (k.in_lds && (k.feat & SMO)) RTK_GO(FEAT | SMO, false, true);
     }
     if constexpr ((FEAT & F_F32_BOX) == 0 && ((FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatMesh || (FEAT & ~uint32_t(F_FMA_BOX | F_MATTE)) == kFeatAll)) {
         if (k.feat & F_LDS_BOXES) RTK_GO(FEAT | uint32_t(F_LDS_BOXES), false, false);  // (slot programs only: see choose_kernel)
@@ -2756,7 +2770,7 @@ hipError_t launch_render(const SceneView<real>& sc, const CameraRec<real>* cam, 
     const KernelChoice k = choose_kernel(sc, features, count, allow_lds, diag);
 #define RTK_LAUNCH_CASE(F) \
     case F: return launch_feat<real, F>(k, sc, cam, tmap, seed, diag, partial, counters, tile_counter, tile_order, tile_cost, stream);
-    switch (k.feat & ~uint32_t(F_LDS_BOXES)) {
+    switch (k.feat & ~uint32_t(F_LDS_BOXES | F_SPHERE_MEDIA_ONLY)) {
 #if !defined(RTK_DEV_ONLY_ALL)   // tools/kernel_resources.py -DRTK_DEV_ONLY_ALL: only the full-feature family (quick register experiments)
         RTK_LAUNCH_CASE(kFeatLean)
         RTK_LAUNCH_CASE(kFeatQuadBox)

@@ -318,7 +318,7 @@ def test_config4_and_config5_full_resolution_reduced_spp_properties(rt, orc, ren
     # (the hot part of the COMPACT program in LDS, the 2 400 quads in memory: F_LDS_BOXES | F_F32_BOX | full feature set) -- the
     # very same doubles, 2 M pixels x 8 samples
     info = renderer.upload_fast(scene, cam.center)
-    assert info["exact"] and info["has_media"] and info["n_ordered_items"] == 2 and "1407u" in renderer.kernel_name()
+    assert info["exact"] and info["has_media"] and info["n_ordered_items"] == 2 and "3455u" in renderer.kernel_name()   # hot/cold COMPACT, sphere media only
     # ... as does the slot program with its boxes in LDS (variant bit 20: f64 boxes, fused slab test)
     assert "1279u" in renderer.kernel_name(variant=1 << 20)
     import torch
@@ -399,7 +399,7 @@ FULL_SIZE_CONFIGS = [
     # config, scene, (W, H, spp, depth), substring of the timed kernel's name
     ("c3", "cornell_box", (800, 800, 1000, 25), "837u"),
     ("c4", "mesh", (1920, 1080, 256, 10), "834u"),
-    ("c5", "book2_final", (1920, 1080, 1000, 10), "1407u"),
+    ("c5", "book2_final", (1920, 1080, 1000, 10), "3455u"),   # full feature | F_F32_BOX | F_LDS_BOXES | F_SPHERE_MEDIA_ONLY
 ]
 
 
@@ -578,8 +578,10 @@ def test_fast_order_on_the_device(rt, orc, renderer, scenes, case):
     # inside a medium's boundary and under instance transforms -- in memory, everything else in LDS): forced by variant bit
     # 23 on the scenes of the full-feature kernel family, which is the only one that has it
     cold_name = renderer.kernel_name(variant=1 << 23)
-    if int(cold_name.split(",")[1].strip().rstrip("u")) & ~(1024 | 256 | 128) == 127:
-        assert "1407u" in cold_name
+    if int(cold_name.split(",")[1].strip().rstrip("u")) & ~(2048 | 1024 | 256 | 128) == 127:
+        # 1407 = full feature | F_F32_BOX | F_LDS_BOXES; + 2048 (F_SPHERE_MEDIA_ONLY) where every medium is sphere-bounded (book 2,
+        # single_fog): the variant without the generic OP_MED_BEGIN / MID / END bracket and its parked query state
+        assert ("3455u" in cold_name) == (name == "book2_final") and ("1407u" in cold_name) == (name != "book2_final")
         cold_img, cold8, _ = renderer.render_host(cam, seed=RENDER_SEED, real_mode=rt.RTK_REAL_F64, variant=1 << 23)
         assert np.array_equal(cold_img, gpu) and np.array_equal(cold8, gpu8)
     else:

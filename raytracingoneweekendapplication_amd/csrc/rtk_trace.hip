@@ -1270,8 +1270,13 @@ RTK_DEV void begin_sample(Lane<real>& L, const CameraRec<real>& cam, int i, int 
 // `radiance` is +0 until then and `pixel_color += radiance` (Camera.txt:72) adds either +0 (sum + 0 == sum: the sum is
 // never -0) or 0 + throughput * background == throughput * background.  Those kernels keep no radiance registers
 // (lean MIXED kernel: 119 -> 113 VGPRs, C2 20.95 -> 20.84 ms, same framebuffer).
+// (round 3) The same holds with emissive materials as long as there are no point lights: a diffuse_light ends the path it
+// emits into (material.h:99-101,116-118), so `radiance` is +0 until then as well and 0 + throughput * emitted == throughput *
+// emitted.  Only get_lighting (Camera.txt:228) adds radiance in the middle of a path.  The quad/box and mesh families (area
+// lights, no point lights) drop six registers of lane state with it: C3's kernel 128 VGPRs + 16 B -> 125 + 0, C4's 128 + 44 B
+// -> 126 + 0 (53.0 -> 51.8 ms).
 template <uint32_t FEAT>
-constexpr bool kNoRadianceState = (FEAT & (F_LIGHTS | F_EXOTIC_MAT)) == 0;
+constexpr bool kNoRadianceState = (FEAT & F_LIGHTS) == 0;
 
 // material::scatter / emitted on a finished hit record (material.h:22-172) and the rest of ray_color's body
 // (Camera.txt:216-237): what shade() runs after it has built the record -- and what the known-answer entry point
@@ -1356,7 +1361,8 @@ RTK_DEV bool shade_surface(Lane<real>& L, const Surface<real>& sf, const SceneVi
     } else {  // diffuse_light / emissive_light: emits, never scatters (material.h:99-101,116-118)
         if (FEAT & F_EXOTIC_MAT) {
             V3<real> emitted = material_color<real, FEAT>(sc, m, sf.u, sf.v, sf.p, cnt);
-            L.radiance = L.radiance + L.throughput * emitted;
+            if constexpr (kNoRadianceState<FEAT>) L.sum = L.sum + L.throughput * emitted;  // = sum + (0 + throughput * emitted), the same bits
+            else L.radiance = L.radiance + L.throughput * emitted;
         }
         return true;
     }
@@ -1567,8 +1573,10 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL, IN_LDS>())) void rtk_r
 #ifndef RTK_DEV_MASK_OFF
 #define RTK_DEV_MASK_OFF 0u   // register-pressure experiments (tools/kernel_resources.py): feature bits compiled out of every kernel
 #endif
-    constexpr uint32_t FEAT = FEAT_ALL & ~uint32_t(F_LDS_BOXES | F_SPHERE_MEDIA_ONLY) & ~uint32_t(RTK_DEV_MASK_OFF);
     constexpr bool BRACKET = (FEAT_ALL & F_SPHERE_MEDIA_ONLY) == 0;  // generic media (OP_MED_BEGIN / MID / END) may occur in the program
+    // (measured and not done: also compiling get_lighting and the radiance registers out of the restricted variant -- 80 instead
+    // of 96 B of scratch, and C5 34.6 instead of 32.0 ms at 32 spp)
+    constexpr uint32_t FEAT = FEAT_ALL & ~uint32_t(F_LDS_BOXES | F_SPHERE_MEDIA_ONLY) & ~uint32_t(RTK_DEV_MASK_OFF);
     constexpr bool LDS_PART = (FEAT_ALL & F_LDS_BOXES) != 0;  // a program larger than LDS, part of it staged there
     static_assert(!LDS_PART || !IN_LDS, "F_LDS_BOXES: for programs that do not fit LDS");
     constexpr bool MIXED = (FEAT & F_F32_BOX) != 0;  // f32 culling boxes + exact primitives (f64 kernels, fast order): ...

@@ -383,6 +383,8 @@ def abi_path_in_child(args, timeout_s):
     for flag, val in (("--width", args.width), ("--height", args.height), ("--spp", args.spp), ("--variant", args.variant)):
         if val:
             cmd += [flag, str(val)]
+    if args.rehearse_one_gpu:  # every rank of the rehearsal shares device 0: so do the child's device slots
+        cmd += ["--multi-devices", ",".join(["0"] * args.gpus)]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RTK_BENCH_CHILD",
                                                               "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
     try:
@@ -728,7 +730,7 @@ def main():
     # ---- N > 1: the product's own multi-GPU path (rtk_render_multi_enqueue behind the C ABI: one process, N devices) beside the
     # torch.distributed ranks that were just timed -- in a child process of rank 0, while every rank idles at a CPU barrier
     multi_paths = None
-    if n > 1 and not args.no_abi_path and not args.rehearse_one_gpu:
+    if n > 1 and not args.no_abi_path:
         idle = dist.new_group(backend="gloo")
         torch.cuda.synchronize()
         dist.barrier(group=idle)

@@ -106,7 +106,14 @@ def test_work_based_fraction_arithmetic():
     pmc = {"SQ_INSTS_VALU": 100.0, "SQ_INSTS_VALU_ADD_F64": 10.0, "SQ_INSTS_VALU_MUL_F64": 10.0, "SQ_INSTS_VALU_FMA_F64": 10.0, "SQ_INSTS_VALU_TRANS_F64": 5.0,
            "SQ_INSTS_VALU_TRANS_F32": 5.0, "SQ_THREAD_CYCLES_VALU": 64.0, "SQ_ACTIVE_INST_VALU": 1.0}
     u = bench.valu_roofline({"counters": pmc}, kernel_ms=1e-6, cycles=cycles)
-    assert abs(u["achieved"] - (30 * 4 + 5 * 16 + 5 * 8 + 60 * 2) / 1e-9 / 1e9) < 1e-3
+    assert abs(u["achieved"] - (30 * 4 + 5 * 16 + 5 * 8 + 60 * 2) / 1e-9 / 1e9) < 1e-3 and u["frac_of_measured_issue_ceiling"] is None
+    # ... and against the measured ceiling: a dense v_fma_f32 stream at the kernel's waves per SIMD (768 threads per CU = 3 waves:
+    # between the 2- and the 4-wave measurement) at the clock the profiled launch held (GRBM_GUI_ACTIVE / 8 XCDs / its duration)
+    pmc2 = dict(pmc, GRBM_GUI_ACTIVE=8 * 2.0e9 * 1e-9)
+    m = bench.valu_roofline({"counters": pmc2, "workgroup": "768", "kernel_ms_profiled": 1e-6}, kernel_ms=1e-6, cycles=cycles, fma_by_waves={"1": 0.2, "2": 0.4, "4": 0.44, "8": 0.45})
+    c = m["frac_of_measured_issue_ceiling"]
+    assert c["waves_per_simd"] == 3.0 and abs(c["v_fma_f32_per_cycle_at_that_occupancy"] - 0.42) < 1e-9 and abs(c["clock_ghz"] - 2.0) < 1e-9
+    assert abs(c["value"] - m["achieved"] / (1024 * 2.0 * 2.0 * 0.42)) < 1e-3
 
 
 def test_isa_cost_table_is_derived_from_the_kernel_sources():
@@ -159,7 +166,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert 1000 < ceil["hbm_copy_GBps"] < 8000 and ceil["lds_read_b128_GBps"] > 10000 and ceil["lds_read_b128_random_records_GBps"] > 1000
     ic = ceil["issue_cycles_per_wave_instruction"]
     assert ic["f32"] == 2.0 and ic["f64"] > ic["f32"] and ic["trans_f32"] > ic["f32"] and ic["trans_f64"] > ic["f64"] and "measured" in ceil["issue_cycles_source"]
-    assert 0.5 < ceil["shader_clock_GHz_under_valu_load"] <= 2.45
+    assert 1.0 < ceil["shader_clock_GHz_under_valu_load"] <= 2.45 and ceil["clock_light_load_GHz"] >= ceil["clock_dense_valu_GHz"] - 0.05
+    by_waves = ceil["issue_v_fma_f32_by_waves_per_simd"]     # one wave alone cannot fill the issue port; eight nearly do (spec: 0.5 per cycle)
+    assert by_waves["1"] < by_waves["2"] <= by_waves["8"] + 0.02 and 0.3 < by_waves["8"] <= 0.52
     assert "work_frac" in r and (r["work_frac"] is None or 0 < r["work_frac"] < 1)
     assert r["hbm_model"]["model_vs_lds_ceiling"] is not None
     c = d["cpu_baseline"]

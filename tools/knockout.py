@@ -26,6 +26,25 @@ class Med(C.Structure):
     _fields_ = [("neg_inv_density", C.c_double), ("material", C.c_int32), ("_pad", C.c_int32)]
 
 
+class Node(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_int32)]
+
+
+def empty_the_media(desc_ptr):
+    """Every constant_medium node becomes an empty hittable_list (hittable_list::hit of no objects: false, no random number drawn).
+    The hierarchy above it keeps its shape and its boxes, so against 'media thin' (same paths: neither scatters) the difference
+    is the cost of the medium steps themselves -- two per segment in book 2's final scene."""
+    ints = (C.c_int32 * 16).from_address(desc_ptr)
+    ptrs = (C.c_void_p * 15).from_address(desc_ptr + 72)
+    nodes = (Node * ints[2]).from_address(ptrs[0])
+    n = 0
+    for node in nodes:
+        if node.kind == 8:
+            node.kind, node.a, node.b, node.c = 4, 0, 0, 0
+            n += 1
+    return n
+
+
 def tables(desc_ptr):
     ints = (C.c_int32 * 16).from_address(desc_ptr)
     ptrs = (C.c_void_p * 15).from_address(desc_ptr + 72)
@@ -78,3 +97,7 @@ if __name__ == "__main__":
                 m.neg_inv_density = -1e30
         t_ms = render(sc, spp, label)
         print(f"    {label}: {100 * (base - t_ms) / base:5.1f} % of the frame", flush=True)
+    sc = fresh()
+    n = empty_the_media(sc.desc_ptr)
+    t_ms = render(sc, spp, f"media emptied ({n} nodes)")
+    print(f"    media emptied: {100 * (base - t_ms) / base:5.1f} % of the frame (against 'media thin': the medium steps themselves)", flush=True)

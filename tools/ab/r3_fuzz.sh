@@ -1,0 +1,3 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
+timeout -k 10 1000 python3 tools/fuzz_parity.py ${FUZZ_N:-150} 50000 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r03_fuzz_parity.txt

@@ -1,0 +1,61 @@
+"""A larger device-vs-oracle sweep than the test suite affords: random scenes (tests/test_fast_order_random.py's generators:
+soups of spheres / quads / triangles with moving spheres, nested lists and rotate_y / translate instances; fog scenes with
+sphere-bounded media inside one another and around the camera), each rendered on the device in the reference order and in
+the fast order and compared with the CPU oracle of the same description at the same seed.
+
+  python3 tools/fuzz_parity.py [n_per_family=100] [first_seed=50000]
+
+Per scene: per-channel RMSE < 1e-12 against the oracle, equal u8 bytes, equal work counters (reference order); the fast
+order's framebuffer equal to the reference order's wherever rtk_scene_optimize reports it exact.  Prints one line per
+failure and a summary; exit code 1 on any failure.  (Test infrastructure: it uses oracle/ as the checker.)
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+import raytracingoneweekendapplication_amd as rt  # noqa: E402
+from oracle import orc  # noqa: E402
+from tests.test_fast_order_random import look_at_camera, random_fog_scene, random_scene  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
+    renderer = rt.Renderer(0)
+    cam = look_at_camera(rt)
+    families = (("soup", lambda s: random_scene(s)), ("soup+triangles", lambda s: random_scene(s, triangles=True)), ("fog", random_fog_scene))
+    failures, worst, total = 0, 0.0, 0
+    kernels = {}
+    for name, make in families:
+        exact_fast = 0
+        for k in range(n):
+            seed = first + k
+            scene = make(seed)
+            ref, ref8, ocnt = orc.render(scene.desc_ptr, cam, 7, 8)
+            renderer.upload(scene)
+            gpu, gpu8, cnt = renderer.render_host(cam, seed=7, count=True)
+            err = float(np.sqrt(np.mean((gpu - ref) ** 2)))
+            worst = max(worst, err)
+            ok = err < 1e-12 and np.array_equal(gpu8, ref8) and cnt == ocnt
+            info = renderer.upload_fast(scene, cam.center)
+            kernels[renderer.kernel_name()] = kernels.get(renderer.kernel_name(), 0) + 1
+            fast, fast8, _ = renderer.render_host(cam, seed=7)
+            if info["exact"]:
+                exact_fast += 1
+                ok = ok and np.array_equal(fast, gpu) and np.array_equal(fast8, gpu8)
+            else:
+                ok = ok and float(np.sqrt(np.mean((fast - ref) ** 2))) < 0.25   # statistically the same picture, other random numbers
+            total += 1
+            if not ok:
+                failures += 1
+                print(f"FAIL {name} seed {seed}: rmse {err:.3e} bytes {np.array_equal(gpu8, ref8)} counters {cnt == ocnt} fast-exact {info['exact']}", flush=True)
+        print(f"{name}: {n} scenes, fast order reported exact for {exact_fast}", flush=True)
+    print(f"{total} scenes, {failures} failures, worst RMSE against the oracle {worst:.3e}; kernels of the fast order: {kernels}", flush=True)
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

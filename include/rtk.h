@@ -100,7 +100,10 @@ typedef struct rtk_translate { rtk_vec3 offset; } rtk_translate;                
 typedef struct rtk_rotate_y { double sin_theta, cos_theta; } rtk_rotate_y;      /* hittable.h:142-143 */
 typedef struct rtk_medium {                                                     /* constant_medium.h:57-59 */
     double neg_inv_density;
-    int32_t material, _pad;  /* the isotropic phase function */
+    int32_t material, _pad;  /* the isotropic phase function.  Its texture is evaluated at the scatter POINT with u = v = 0:
+                              * constant_medium::hit leaves rec.u / rec.v as the record held them (constant_medium.h:45-50), so in
+                              * the reference an image or uv-checker texture there reads whatever an earlier hit() wrote -- not
+                              * reproduced (solid colours, checkers over the point and noise textures are exact). */
 } rtk_medium;
 
 typedef enum rtk_material_kind {

@@ -49,6 +49,18 @@ class Texture(C.Structure):
     _fields_ = [("kind", C.c_int32), ("even", C.c_int32), ("odd", C.c_int32), ("image", C.c_int32), ("color", Vec3), ("param", C.c_double)]
 
 
+class Image(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("texel_offset", C.c_int64)]
+
+
+class Perlin(C.Structure):
+    _fields_ = [("randvec", (C.c_double * 3) * 256), ("perm_x", C.c_int32 * 256), ("perm_y", C.c_int32 * 256), ("perm_z", C.c_int32 * 256)]
+
+
+class PointLight(C.Structure):
+    _fields_ = [("position", Vec3), ("intensity", Vec3), ("size", C.c_double)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("root", C.c_int32), ("n_nodes", C.c_int32), ("n_list_children", C.c_int32), ("n_spheres", C.c_int32),
                 ("n_quads", C.c_int32), ("n_triangles", C.c_int32), ("n_bvh_boxes", C.c_int32), ("n_translates", C.c_int32), ("n_rotates", C.c_int32),
@@ -62,7 +74,7 @@ class SceneDesc(C.Structure):
 
 NODE_SPHERE, NODE_QUAD, NODE_TRIANGLE, NODE_LIST, NODE_BVH, NODE_TRANSLATE, NODE_ROTATE_Y, NODE_MEDIUM = range(1, 9)
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC, MAT_SPECULAR = range(1, 7)
-TEX_SOLID = 1
+TEX_SOLID, TEX_CHECKER, TEX_CHECKER_TRI, TEX_IMAGE, TEX_NOISE = range(1, 6)
 
 
 def _union(boxes):
@@ -84,6 +96,7 @@ class DescBuilder:
         self.nodes, self.children, self.spheres, self.quads, self.translates, self.rotates, self.media = [], [], [], [], [], [], []
         self.triangles = []
         self.materials, self.textures = [], []
+        self.images, self.texels, self.perlins, self.lights = [], bytearray(), [], []
         self.boxes = []       # rtk_aabb of the bvh nodes
         self.box_of = {}      # node -> (xmin, xmax, ymin, ymax, zmin, zmax) where the builder knows it (spheres and what is made of them)
 
@@ -94,6 +107,47 @@ class DescBuilder:
     def solid(self, rgb):
         self.textures.append(Texture(TEX_SOLID, 0, 0, 0, Vec3(*rgb), 0.0))
         return len(self.textures) - 1
+
+    def checker(self, scale, even, odd, by_uv=False):
+        """checker_texture (texture.h:34-56) over two textures, or the uv form (texture.h:58-84); param = 1 / scale."""
+        self.textures.append(Texture(TEX_CHECKER_TRI if by_uv else TEX_CHECKER, even, odd, 0, Vec3(0, 0, 0), 1.0 / scale))
+        return len(self.textures) - 1
+
+    def noise(self, scale, rnd):
+        """noise_texture (texture.h:110-120) over a perlin table filled the way perlin.h:6-13,59-70 fills it, from `rnd`."""
+        pn = Perlin()
+        for i in range(256):
+            v = [rnd.uniform(-1, 1) for _ in range(3)]
+            n = math.sqrt(sum(c * c for c in v)) or 1.0
+            for k in range(3):
+                pn.randvec[i][k] = v[k] / n
+        for perm in (pn.perm_x, pn.perm_y, pn.perm_z):
+            order = list(range(256))
+            rnd.shuffle(order)
+            for i in range(256):
+                perm[i] = order[i]
+        self.perlins.append(pn)
+        self.textures.append(Texture(TEX_NOISE, 0, 0, len(self.perlins) - 1, Vec3(0, 0, 0), scale))
+        return len(self.textures) - 1
+
+    def image(self, width, height, rnd):
+        """image_texture (texture.h:86-108) over random RGB8 texels (rtw_stb_image.h:71-81); width 0 = the missing-file colour."""
+        self.images.append(Image(width, height, len(self.texels)))
+        self.texels += bytes(rnd.randrange(256) for _ in range(width * height * 3))
+        self.textures.append(Texture(TEX_IMAGE, 0, 0, len(self.images) - 1, Vec3(0, 0, 0), 0.0))
+        return len(self.textures) - 1
+
+    def textured(self, texture, kind=MAT_LAMBERTIAN):
+        """lambertian / diffuse_light / isotropic over any texture."""
+        self.materials.append(Material(kind, texture, Vec3(0, 0, 0), 0.0))
+        return len(self.materials) - 1
+
+    def specular(self, rgb, shininess):
+        self.materials.append(Material(MAT_SPECULAR, -1, Vec3(*rgb), shininess))
+        return len(self.materials) - 1
+
+    def point_light(self, position, intensity, size):
+        self.lights.append(PointLight(Vec3(*position), Vec3(*intensity), size))
 
     def lambertian(self, rgb):
         self.materials.append(Material(MAT_LAMBERTIAN, self.solid(rgb), Vec3(0, 0, 0), 0.0))
@@ -204,6 +258,8 @@ class BuiltDesc:
         self._keep = dict(nodes=arr(Node, b.nodes), children=(C.c_int32 * max(1, len(b.children)))(*b.children), spheres=arr(Sphere, b.spheres),
                           quads=arr(Quad, b.quads), translates=arr(Translate, b.translates), rotates=arr(RotateY, b.rotates), media=arr(Medium, b.media),
                           materials=arr(Material, b.materials), textures=arr(Texture, b.textures), tris=arr(Triangle, b.triangles), boxes=arr(Aabb, b.boxes))
+        self._keep.update(images=arr(Image, b.images), texels=(C.c_uint8 * max(1, len(b.texels))).from_buffer_copy(bytes(b.texels) or b"\0"),
+                          perlins=arr(Perlin, b.perlins), lights=arr(PointLight, b.lights))
         k = self._keep
         d = SceneDesc()
         d.abi_version, d.root = 2, root  # RTK_ABI_VERSION
@@ -214,6 +270,9 @@ class BuiltDesc:
         d.nodes, d.list_children, d.spheres, d.quads = k["nodes"], k["children"], k["spheres"], k["quads"]
         d.triangles, d.bvh_boxes, d.translates, d.rotates = k["tris"], k["boxes"], k["translates"], k["rotates"]
         d.media, d.materials, d.textures = k["media"], k["materials"], k["textures"]
+        d.n_images, d.n_perlins, d.n_lights, d.n_texel_bytes = len(b.images), len(b.perlins), len(b.lights), len(b.texels)
+        d.images, d.texels = C.cast(k["images"], C.c_void_p), C.cast(k["texels"], C.c_void_p)
+        d.perlins, d.lights = C.cast(k["perlins"], C.c_void_p), C.cast(k["lights"], C.c_void_p)
         self.desc = d
         self.name = "built"
 

@@ -726,6 +726,26 @@ def test_random_soups_on_the_device(rt, orc, renderer, seed, triangles):
         assert fcnt[key] == cnt[key], key
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_random_zoo_scenes_on_the_device(rt, orc, renderer, seed):
+    """Random scenes with every feature at once (tests/test_fast_order_random.py::random_zoo_scene: seven materials, five textures,
+    a textured medium, point lights, triangles and quads under instances): the full-feature kernels agree with the oracle in the
+    reference order, work counters included, and the fast order renders the same doubles."""
+    from tests.test_fast_order_random import look_at_camera, random_zoo_scene
+
+    scene = random_zoo_scene(8000 + seed)
+    cam = look_at_camera(rt)
+    ref, ref8, ocnt = orc.render(scene.desc_ptr, cam, 7, 4)
+    renderer.upload(scene)
+    gpu, gpu8, cnt = renderer.render_host(cam, seed=7, count=True)
+    assert rmse(gpu, ref) < F64_RMSE_BOUND and np.array_equal(gpu8, ref8) and cnt == ocnt
+    info = renderer.upload_fast(scene, cam.center)
+    assert info["exact"]
+    fast, fast8, _ = renderer.render_host(cam, seed=7)
+    assert np.array_equal(fast, gpu) and np.array_equal(fast8, gpu8)
+
+
 def test_cpp_camera_render_through_the_drop_in_api(rt, tmp_path):
     """The C++ side of the boundary end to end (host/rtk_camera.h): a reference-style program builds its scene with the
     drop-in classes and calls camera::render_to.  auto_order must pick the fast order exactly when it is bit-identical

@@ -1,6 +1,7 @@
 """A larger device-vs-oracle sweep than the test suite affords: random scenes (tests/test_fast_order_random.py's generators:
 soups of spheres / quads / triangles with moving spheres, nested lists and rotate_y / translate instances; fog scenes with
-sphere-bounded media inside one another and around the camera), each rendered on the device in the reference order and in
+sphere-bounded media inside one another and around the camera; "zoo" scenes with all seven materials, the five textures, a
+textured medium and point lights), each rendered on the device in the reference order and in
 the fast order and compared with the CPU oracle of the same description at the same seed.
 
   python3 tools/fuzz_parity.py [n_per_family=100] [first_seed=50000]
@@ -18,7 +19,7 @@ import numpy as np  # noqa: E402
 
 import raytracingoneweekendapplication_amd as rt  # noqa: E402
 from oracle import orc  # noqa: E402
-from tests.test_fast_order_random import look_at_camera, random_fog_scene, random_scene  # noqa: E402
+from tests.test_fast_order_random import look_at_camera, random_fog_scene, random_scene, random_zoo_scene  # noqa: E402
 
 
 def main():
@@ -26,7 +27,7 @@ def main():
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
     renderer = rt.Renderer(0)
     cam = look_at_camera(rt)
-    families = (("soup", lambda s: random_scene(s)), ("soup+triangles", lambda s: random_scene(s, triangles=True)), ("fog", random_fog_scene))
+    families = (("soup", lambda s: random_scene(s)), ("soup+triangles", lambda s: random_scene(s, triangles=True)), ("fog", random_fog_scene), ("zoo", random_zoo_scene))
     failures, worst, total = 0, 0.0, 0
     kernels = {}
     for name, make in families:

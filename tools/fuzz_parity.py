@@ -22,11 +22,23 @@ from oracle import orc  # noqa: E402
 from tests.test_fast_order_random import look_at_camera, random_fog_scene, random_scene, random_zoo_scene  # noqa: E402
 
 
+def random_camera(rnd):
+    """A camera of its own for every scene: ragged sizes (not multiples of the 8x8 tile), aspect ratios, fields of view, a lens or
+    none, 1-6 samples, depth 1-9, a background colour (Camera.txt:136-175 through host/rtk_camera.h)."""
+    cam = rt.derive_camera(rnd.randint(17, 90), rnd.choice([16 / 9, 1.0, 4 / 3, 2.35, 0.7]), spp=rnd.randint(1, 6), max_depth=rnd.randint(1, 9),
+                           vfov=rnd.uniform(30, 100), lookfrom=(rnd.uniform(-1, 1), rnd.uniform(-0.3, 1.5), rnd.uniform(-0.5, 1.5)),
+                           lookat=(rnd.uniform(-1, 1), rnd.uniform(-0.5, 1), rnd.uniform(-6, -4)), defocus_angle=rnd.choice([0.0, 0.0, 0.6, 2.5]),
+                           focus_dist=rnd.uniform(3, 8))
+    cam.background = rt.Vec3(rnd.uniform(0, 1), rnd.uniform(0, 1), rnd.uniform(0, 1))
+    return cam
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
     renderer = rt.Renderer(0)
-    cam = look_at_camera(rt)
+    import random
+    fixed = look_at_camera(rt)
     families = (("soup", lambda s: random_scene(s)), ("soup+triangles", lambda s: random_scene(s, triangles=True)), ("fog", random_fog_scene), ("zoo", random_zoo_scene))
     failures, worst, total = 0, 0.0, 0
     kernels = {}
@@ -35,6 +47,7 @@ def main():
         for k in range(n):
             seed = first + k
             scene = make(seed)
+            cam = fixed if k % 2 == 0 else random_camera(random.Random(seed))   # every other scene through a camera of its own
             ref, ref8, ocnt = orc.render(scene.desc_ptr, cam, 7, 8)
             renderer.upload(scene)
             gpu, gpu8, cnt = renderer.render_host(cam, seed=7, count=True)

@@ -180,7 +180,14 @@ class DescBuilder:
         normal = tuple((1 / length) * c for c in n)        # unit_vector: v / length = (1/length) * v (vec3.h:91-93,104-106)
         w = tuple((1 / nn) * c for c in n)                 # n / dot(n, n)
         self.quads.append(Quad(Vec3(*Q), Vec3(*u), Vec3(*v), Vec3(*w), Vec3(*normal), _dot(normal, Q), material, 0))
-        return self._node(NODE_QUAD, len(self.quads) - 1)
+        node = self._node(NODE_QUAD, len(self.quads) - 1)
+        corners = [Q, tuple(Q[k] + u[k] for k in range(3)), tuple(Q[k] + v[k] for k in range(3)), tuple(Q[k] + u[k] + v[k] for k in range(3))]
+        self.box_of[node] = self._padded(corners)            # a bounding box of the four corners (quad.h:21-26 pads thin boxes as well)
+        return node
+
+    @staticmethod
+    def _padded(points, pad=1e-4):
+        return tuple(f(p[k] for p in points) + sgn * pad for k in range(3) for f, sgn in ((min, -1), (max, 1)))
 
     def triangle(self, p0, p1, p2, material, uvs=((0.0, 0.0), (1.0, 0.0), (0.0, 1.0))):
         e1 = tuple(p1[k] - p0[k] for k in range(3))          # triangle.h:21-23: n = cross(p1 - p0, p2 - p0), normal = unit_vector(n)
@@ -190,7 +197,9 @@ class DescBuilder:
         normal = tuple((1 / length) * c for c in n)
         f2 = C.c_float * 2
         self.triangles.append(Triangle(Vec3(*p0), Vec3(*p1), Vec3(*p2), Vec3(*normal), f2(*uvs[0]), f2(*uvs[1]), f2(*uvs[2]), material, 0))
-        return self._node(NODE_TRIANGLE, len(self.triangles) - 1)
+        node = self._node(NODE_TRIANGLE, len(self.triangles) - 1)
+        self.box_of[node] = self._padded([p0, p1, p2])
+        return node
 
     def rank(self, node, rank):
         """rtk_node.c of a primitive node: 1 + its rank in the reference's visiting order (what rtk_scene_optimize records)."""

@@ -107,6 +107,38 @@ def random_zoo_scene(seed):
     return b.finish(b.list(top))
 
 
+def random_big_scene(seed, n_prims=None):
+    """Thousands of small primitives under the reference's kind of hierarchy (a bvh_node over everything, bvh.h:13-45): a
+    traversal program that does not fit the 160 KB of LDS, so the device runs its boxes-in-LDS / hot-cold kernels -- on content
+    no named scene has (spheres static and moving, quads and triangles mixed, three materials, a light, a fog ball)."""
+    rnd = random.Random(seed)
+    b = DescBuilder()
+    mats = [b.lambertian((rnd.random(), rnd.random(), rnd.random())) for _ in range(3)]
+    mats += [b.metal((0.8, 0.7, 0.6), rnd.random() * 0.4), b.dielectric(1.5), b.light((4.0, 4.0, 3.5))]
+    n = n_prims or rnd.randint(1800, 4200)
+    kinds = rnd.choice([(1.0, 0.0), (0.5, 0.5), (0.4, 0.3), (0.0, 1.0)])     # (share of spheres, share of quads): the rest are triangles
+    members = [b.sphere((0, -101, -5), 100.0, mats[0])]
+    for _ in range(n):
+        c = (rnd.uniform(-6, 6), rnd.uniform(-0.9, 4), rnd.uniform(-12, -2))
+        m = rnd.choice(mats)
+        r = rnd.random()
+        if r < kinds[0]:
+            motion = (rnd.uniform(-0.1, 0.1), rnd.uniform(-0.1, 0.1), 0.0) if rnd.random() < 0.1 else (0.0, 0.0, 0.0)
+            members.append(b.sphere(c, rnd.uniform(0.03, 0.2), m, motion))
+            continue
+        u = (rnd.uniform(0.1, 0.4), rnd.uniform(-0.1, 0.1), rnd.uniform(-0.15, 0.15))
+        v = (rnd.uniform(-0.1, 0.1), rnd.uniform(0.1, 0.4), rnd.uniform(-0.15, 0.15))
+        if r < kinds[0] + kinds[1]:
+            members.append(b.quad(c, u, v, m))
+        else:
+            members.append(b.triangle(c, tuple(c[k] + u[k] for k in range(3)), tuple(c[k] + v[k] for k in range(3)), m))
+    top = [b.bvh(members, rnd)]
+    if rnd.random() < 0.5:
+        shell = b.sphere((rnd.uniform(-2, 2), rnd.uniform(0, 1.5), rnd.uniform(-6, -3)), rnd.uniform(0.7, 1.6), mats[4])
+        top += [b.medium(shell, rnd.uniform(0.3, 2.0), (rnd.random(), rnd.random(), rnd.random())), shell]
+    return b.finish(b.list(top))
+
+
 def look_at_camera(rt):
     cam = rt.Scene.build("three_spheres").camera(48, 27, 3, 6)   # at the origin, looking down -z: the soup lies in front of it
     return cam
@@ -157,6 +189,22 @@ def test_random_zoo_scenes_render_identically_in_the_fast_order(rt, orc, seed):
     got, got8, gc = orc.render(fast.desc_ptr, cam, 7, 4)
     assert np.array_equal(got, ref) and np.array_equal(got8, ref8), f"seed {seed}: max diff {np.abs(got - ref).max()}"
     for k in ("segments", "surface_hits", "rng_draws", "noise_calls", "texel_fetches"):
+        assert gc[k] == rc[k], k
+    assert ref.std() > 0.01
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_big_scenes_render_identically_in_the_fast_order(rt, orc, seed):
+    """Thousands of primitives under a reference-style bvh_node (programs larger than LDS on the device): the re-grouped
+    hierarchy renders the same doubles with far fewer primitive tests."""
+    scene = random_big_scene(9000 + seed, n_prims=2500)
+    cam = look_at_camera(rt)
+    ref, ref8, rc = orc.render(scene.desc_ptr, cam, 7, 4)
+    fast = rt.FastOrderScene(scene, cam.center)
+    assert fast.exact
+    got, got8, gc = orc.render(fast.desc_ptr, cam, 7, 4)
+    assert np.array_equal(got, ref) and np.array_equal(got8, ref8), f"seed {seed}: max diff {np.abs(got - ref).max()}"
+    for k in ("segments", "surface_hits", "rng_draws"):
         assert gc[k] == rc[k], k
     assert ref.std() > 0.01
 

@@ -746,6 +746,27 @@ def test_random_zoo_scenes_on_the_device(rt, orc, renderer, seed):
     assert np.array_equal(fast, gpu) and np.array_equal(fast8, gpu8)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(3))
+def test_random_big_scenes_on_the_device(rt, orc, renderer, seed):
+    """Random scenes of a few thousand primitives (tests/test_fast_order_random.py::random_big_scene): the traversal program is
+    larger than LDS, so these run the kernels that keep only a part of it there -- against the oracle in the reference order,
+    and bit-identical in the fast order."""
+    from tests.test_fast_order_random import look_at_camera, random_big_scene
+
+    scene = random_big_scene(9100 + seed)
+    cam = look_at_camera(rt)
+    ref, ref8, ocnt = orc.render(scene.desc_ptr, cam, 7, 4)
+    renderer.upload(scene)
+    assert renderer.kernel_name().rstrip(">").endswith("false")        # not the all-in-LDS instantiation
+    gpu, gpu8, cnt = renderer.render_host(cam, seed=7, count=True)
+    assert rmse(gpu, ref) < F64_RMSE_BOUND and np.array_equal(gpu8, ref8) and cnt == ocnt
+    info = renderer.upload_fast(scene, cam.center)
+    assert info["exact"]
+    fast, fast8, _ = renderer.render_host(cam, seed=7)
+    assert np.array_equal(fast, gpu) and np.array_equal(fast8, gpu8)
+
+
 def test_cpp_camera_render_through_the_drop_in_api(rt, tmp_path):
     """The C++ side of the boundary end to end (host/rtk_camera.h): a reference-style program builds its scene with the
     drop-in classes and calls camera::render_to.  auto_order must pick the fast order exactly when it is bit-identical

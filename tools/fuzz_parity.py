@@ -1,7 +1,7 @@
 """A larger device-vs-oracle sweep than the test suite affords: random scenes (tests/test_fast_order_random.py's generators:
 soups of spheres / quads / triangles with moving spheres, nested lists and rotate_y / translate instances; fog scenes with
 sphere-bounded media inside one another and around the camera; "zoo" scenes with all seven materials, the five textures, a
-textured medium and point lights), each rendered on the device in the reference order and in
+textured medium and point lights; "big" scenes of 1 800 - 4 200 primitives whose traversal program does not fit LDS), each rendered on the device in the reference order and in
 the fast order and compared with the CPU oracle of the same description at the same seed.
 
   python3 tools/fuzz_parity.py [n_per_family=100] [first_seed=50000]
@@ -19,7 +19,7 @@ import numpy as np  # noqa: E402
 
 import raytracingoneweekendapplication_amd as rt  # noqa: E402
 from oracle import orc  # noqa: E402
-from tests.test_fast_order_random import look_at_camera, random_fog_scene, random_scene, random_zoo_scene  # noqa: E402
+from tests.test_fast_order_random import look_at_camera, random_fog_scene, random_big_scene, random_scene, random_zoo_scene  # noqa: E402
 
 
 def random_camera(rnd):
@@ -39,12 +39,14 @@ def main():
     renderer = rt.Renderer(0)
     import random
     fixed = look_at_camera(rt)
-    families = (("soup", lambda s: random_scene(s)), ("soup+triangles", lambda s: random_scene(s, triangles=True)), ("fog", random_fog_scene), ("zoo", random_zoo_scene))
+    families = (("soup", lambda s: random_scene(s)), ("soup+triangles", lambda s: random_scene(s, triangles=True)), ("fog", random_fog_scene), ("zoo", random_zoo_scene),
+                ("big (programs larger than LDS)", random_big_scene))
     failures, worst, total = 0, 0.0, 0
     kernels = {}
     for name, make in families:
         exact_fast = 0
-        for k in range(n):
+        count = max(4, n // 10) if name.startswith("big") else n      # thousands of primitives each: a tenth as many scenes
+        for k in range(count):
             seed = first + k
             scene = make(seed)
             cam = fixed if k % 2 == 0 else random_camera(random.Random(seed))   # every other scene through a camera of its own
@@ -66,7 +68,7 @@ def main():
             if not ok:
                 failures += 1
                 print(f"FAIL {name} seed {seed}: rmse {err:.3e} bytes {np.array_equal(gpu8, ref8)} counters {cnt == ocnt} fast-exact {info['exact']}", flush=True)
-        print(f"{name}: {n} scenes, fast order reported exact for {exact_fast}", flush=True)
+        print(f"{name}: {count} scenes, fast order reported exact for {exact_fast}", flush=True)
     print(f"{total} scenes, {failures} failures, worst RMSE against the oracle {worst:.3e}; kernels of the fast order: {kernels}", flush=True)
     return 1 if failures else 0
 

@@ -13,7 +13,9 @@ device is usable, ``Renderer`` raises; nothing falls back to the oracle.
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 from typing import Optional
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -175,12 +177,26 @@ def host_lib() -> C.CDLL:
     return _host_lib
 
 
+def _one_hip_runtime() -> None:
+    """One HIP runtime per process.  librtk_hip.so links /opt/rocm's libamdhip64; a PyTorch-ROCm wheel carries its own copy, and
+    whichever runtime touches the devices FIRST owns them -- a process that rendered before it imported torch finds torch.cuda
+    without devices ("No HIP GPUs are available").  With torch loaded first the library's HIP calls bind to torch's runtime (its
+    libraries sit in the global symbol scope), which is also what makes torch streams and data_ptr()s valid arguments of the C
+    ABI.  So where torch is installed it is imported before a HIP library of this package is loaded."""
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        try:
+            import torch  # noqa: F401
+        except Exception:   # a broken torch install must not take the renderer down with it
+            pass
+
+
 def hip_lib() -> C.CDLL:
     """librtk_hip.so: the kernels + C ABI.  Raises if it was not built."""
     global _hip_lib
     if _hip_lib is None:
         if not os.path.exists(HIP_LIB_PATH):
             raise RuntimeError(f"{HIP_LIB_PATH} not built: the HIP extension is required, there is no CPU path")
+        _one_hip_runtime()
         lib = C.CDLL(HIP_LIB_PATH)
         lib.rtk_abi_version.restype = C.c_int
         lib.rtk_last_error.restype = C.c_char_p
@@ -237,6 +253,7 @@ def microbench(device: int = 0) -> dict:
     A measurement tool for bench.py's roofline object; raises when the library or a device is missing."""
     if not os.path.exists(MICROBENCH_LIB_PATH):
         raise RuntimeError(f"{MICROBENCH_LIB_PATH} not built (run __graft_entry__.build())")
+    _one_hip_runtime()
     lib = C.CDLL(MICROBENCH_LIB_PATH)
     lib.rtk_microbench_names.restype = C.c_char_p
     lib.rtk_microbench_last_error.restype = C.c_char_p

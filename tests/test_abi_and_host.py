@@ -6,6 +6,7 @@ import json
 import os
 import re
 import subprocess
+import sys
 import tempfile
 
 import numpy as np
@@ -338,3 +339,16 @@ def test_reference_main_cpp_compiles_unmodified_against_the_drop_in_headers(rt, 
                            "-I" + os.path.join(pkg, "host", "compat"), "-I" + os.path.join(ROOT, "include"), "-L" + pkg, "-lrtk_hip",
                            "-Wl,-rpath," + pkg, "-o", str(exe)])
     assert exe.exists()
+
+
+def test_the_library_is_loaded_after_torch_so_that_one_hip_runtime_serves_both():
+    """A PyTorch-ROCm wheel carries its own libamdhip64; a process whose first HIP call came from /opt/rocm's copy (through
+    librtk_hip.so) finds torch.cuda without devices afterwards.  The package therefore imports torch (where installed) before it
+    loads its library -- checked in a fresh interpreter that never mentions torch itself."""
+    code = ("import sys, raytracingoneweekendapplication_amd as rt\n"
+            "assert 'torch' not in sys.modules\n"
+            "rt.hip_lib()\n"
+            "import importlib.util\n"
+            "assert ('torch' in sys.modules) == (importlib.util.find_spec('torch') is not None)\n")
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]

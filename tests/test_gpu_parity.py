@@ -14,11 +14,13 @@ Tolerances
       Only statistical agreement is asserted: image mean within 2 %, work-counter totals within 10 %.
 """
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 
-from tests.conftest import EARTH, GOLDEN
+from tests.conftest import EARTH, GOLDEN, ROOT
 from tests.scene_cases import IMAGE_CASES, RENDER_SEED, SCENE_SEED, scene_file
 
 pytestmark = pytest.mark.gpu
@@ -765,6 +767,24 @@ def test_random_big_scenes_on_the_device(rt, orc, renderer, seed):
     assert info["exact"]
     fast, fast8, _ = renderer.render_host(cam, seed=7)
     assert np.array_equal(fast, gpu) and np.array_equal(fast8, gpu8)
+
+
+@pytest.mark.gpu
+def test_rendering_before_importing_torch_leaves_torch_its_devices():
+    """One HIP runtime per process (raytracingoneweekendapplication_amd._one_hip_runtime): a script that renders first and only
+    then imports torch still gets torch.cuda, and a torch tensor is a valid render target."""
+    code = ("import raytracingoneweekendapplication_amd as rt\n"
+            "scene = rt.Scene.build('three_spheres'); cam = scene.camera(32, 18, 2, 4)\n"
+            "r = rt.Renderer(0); r.upload(scene)\n"
+            "a, _, _ = r.render_host(cam)\n"
+            "import torch\n"
+            "assert torch.cuda.is_available() and torch.cuda.device_count() >= 1\n"
+            "img = torch.empty((18, 32, 3), dtype=torch.float64, device='cuda:0')\n"
+            "r.render_device(cam, img.data_ptr(), 0); torch.cuda.synchronize()\n"
+            "import numpy as np\n"
+            "assert np.array_equal(img.cpu().numpy(), a)\n")
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
 
 
 def test_cpp_camera_render_through_the_drop_in_api(rt, tmp_path):

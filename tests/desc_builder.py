@@ -194,7 +194,8 @@ class DescBuilder:
         e2 = tuple(p2[k] - p0[k] for k in range(3))
         n = _cross(e1, e2)
         length = math.sqrt(_dot(n, n))
-        normal = tuple((1 / length) * c for c in n)
+        inv = 1 / length if length > 0 else math.inf        # a zero-area triangle: (1/0) * 0 = NaN components, as in C++
+        normal = tuple(inv * c for c in n)
         f2 = C.c_float * 2
         self.triangles.append(Triangle(Vec3(*p0), Vec3(*p1), Vec3(*p2), Vec3(*normal), f2(*uvs[0]), f2(*uvs[1]), f2(*uvs[2]), material, 0))
         node = self._node(NODE_TRIANGLE, len(self.triangles) - 1)

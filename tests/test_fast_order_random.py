@@ -139,6 +139,75 @@ def random_big_scene(seed, n_prims=None):
     return b.finish(b.list(top))
 
 
+def random_sphere_scene(seed):
+    """Spheres only -- what the lean MIXED kernel (the headline kernel: f32 centre / half-extent culling boxes, f64 spheres) runs:
+    5 to 700 of them, static and moving, the three book-1 materials, radii over four orders of magnitude, clusters far from the
+    origin (the float boxes' error budget scales with the coordinates), spheres inside spheres and around the camera."""
+    rnd = random.Random(seed)
+    b = DescBuilder()
+    mats = [b.lambertian((rnd.random(), rnd.random(), rnd.random())) for _ in range(4)]
+    mats += [b.metal((0.8, 0.7, 0.6), rnd.random() * 0.5), b.metal((0.9, 0.9, 0.9), 0.0), b.dielectric(1.5), b.dielectric(1 / 1.5)]
+    top = [b.sphere((0, -1001, -5), 1000.0, mats[0])]
+    n = rnd.choice([5, 20, 80, 300, 700])
+    far = rnd.choice([0.0, 0.0, 300.0, 5000.0])              # a second cluster far away (seen small, or not at all)
+    for k in range(n):
+        c = (rnd.uniform(-5, 5), rnd.uniform(-0.9, 3), rnd.uniform(-12, -2))
+        if far and k % 3 == 0:
+            c = (c[0] + far, c[1], c[2] - far)
+        r = rnd.choice([0.02, 0.1, 0.3, 0.3, 0.8, 2.0]) * rnd.uniform(0.5, 1.5)
+        motion = (rnd.uniform(-0.4, 0.4), rnd.uniform(-0.3, 0.3), rnd.uniform(-0.2, 0.2)) if rnd.random() < 0.15 else (0.0, 0.0, 0.0)
+        top.append(b.sphere(c, r, rnd.choice(mats), motion))
+        if rnd.random() < 0.05:
+            top.append(b.sphere(c, 0.5 * r, rnd.choice(mats)))       # one inside the other (a bubble, main.cpp:25-26)
+    if rnd.random() < 0.2:
+        top.append(b.sphere((0.0, 0.5, 0.0), rnd.uniform(20, 40), mats[6]))   # a glass ball around the camera and the scene
+    rnd.shuffle(top)
+    return b.finish(b.list(top))
+
+
+def random_degenerate_scene(seed):
+    """Soups seeded with the cases closest-hit code gets wrong first: the same primitive listed twice with two materials and
+    coplanar overlapping quads / triangles (exact ties: the reference's visiting order decides, hittable_list.h:29-33,
+    interval::surrounds vs contains), spheres of radius 0 (sphere.h:14 fmax(0, r)), a zero-area triangle and a needle quad,
+    a sphere around the camera, glass of index 1, metal of fuzz 0 and 1, primitives touching one another."""
+    rnd = random.Random(seed)
+    b = DescBuilder()
+    mats = [b.lambertian((rnd.random(), rnd.random(), rnd.random())) for _ in range(3)]
+    mats += [b.metal((0.8, 0.7, 0.6), 0.0), b.metal((0.6, 0.7, 0.8), 1.0), b.dielectric(1.0), b.dielectric(1.5), b.light((4.0, 4.0, 3.5))]
+    top = [b.sphere((0, -101, -5), 100.0, mats[0])]
+    for _ in range(rnd.randint(5, 10)):
+        m, m2 = rnd.choice(mats), rnd.choice(mats)
+        c = (rnd.uniform(-3, 3), rnd.uniform(-0.8, 2), rnd.uniform(-7, -2.5))
+        u = (rnd.uniform(0.5, 1.6), 0.0, 0.0)
+        v = (0.0, rnd.uniform(0.5, 1.6), 0.0)
+        case = rnd.randrange(9)
+        if case == 0:      # the same sphere twice, two materials
+            r = rnd.uniform(0.3, 0.9)
+            top += [b.sphere(c, r, m), b.sphere(c, r, m2)]
+        elif case == 1:    # the same quad twice
+            top += [b.quad(c, u, v, m), b.quad(c, u, v, m2)]
+        elif case == 2:    # coplanar, overlapping, axis-aligned quads (the overlap is an exact tie for every ray)
+            top += [b.quad(c, u, v, m), b.quad((c[0] + 0.25 * u[0], c[1] + 0.25 * v[1], c[2]), u, v, m2)]
+        elif case == 3:    # a triangle lying in a quad
+            top += [b.quad(c, u, v, m), b.triangle(c, (c[0] + u[0], c[1], c[2]), (c[0], c[1] + v[1], c[2]), m2)]
+        elif case == 4:    # radius 0 and a negative radius (both: a point nobody hits), next to a real sphere
+            top += [b.sphere(c, 0.0, m), b.sphere((c[0] + 0.1, c[1], c[2]), -0.5, m2), b.sphere((c[0], c[1] + 0.5, c[2]), 0.4, m)]
+        elif case == 5:    # a zero-area triangle and a needle
+            top += [b.triangle(c, c, (c[0] + 1, c[1], c[2]), m), b.quad(c, (1.5, 0.0, 0.0), (1.5, 1e-9, 0.0), m2) if False else b.quad(c, (1.5, 0.0, 0.0), (0.0, 1e-7, 0.0), m2)]
+        elif case == 6:    # two spheres touching in one point, and one inside the other
+            r = rnd.uniform(0.3, 0.7)
+            top += [b.sphere(c, r, m), b.sphere((c[0] + 2 * r, c[1], c[2]), r, m2), b.sphere(c, 0.5 * r, m2)]
+        elif case == 7:    # a big sphere around the camera (every primary ray starts inside it)
+            top.append(b.sphere((0.0, 0.0, 0.0), rnd.uniform(9, 14), rnd.choice(mats[:3] + [mats[6]])))
+        else:
+            top.append(b.sphere(c, rnd.uniform(0.2, 0.9), m, (rnd.uniform(-0.3, 0.3), 0.0, 0.0)))
+    if rnd.random() < 0.4:
+        inst = b.translate(b.rotate_y(b.list([top.pop(), top.pop()]), rnd.uniform(-30, 30)), (rnd.uniform(-0.5, 0.5), 0.0, 0.0))
+        top.append(inst)
+    rnd.shuffle(top)
+    return b.finish(b.list(top))
+
+
 def look_at_camera(rt):
     cam = rt.Scene.build("three_spheres").camera(48, 27, 3, 6)   # at the origin, looking down -z: the soup lies in front of it
     return cam
@@ -207,6 +276,35 @@ def test_random_big_scenes_render_identically_in_the_fast_order(rt, orc, seed):
     for k in ("segments", "surface_hits", "rng_draws"):
         assert gc[k] == rc[k], k
     assert ref.std() > 0.01
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_sphere_scenes_render_identically_in_the_fast_order(rt, orc, seed):
+    """Sphere-only scenes (the lean MIXED kernel's domain): proven exact, and the re-grouped hierarchy renders the same doubles."""
+    scene = random_sphere_scene(12000 + seed)
+    cam = look_at_camera(rt)
+    ref, ref8, rc = orc.render(scene.desc_ptr, cam, 7, 4)
+    fast = rt.FastOrderScene(scene, cam.center)
+    assert fast.exact and fast.proven
+    got, got8, gc = orc.render(fast.desc_ptr, cam, 7, 4)
+    assert np.array_equal(got, ref) and np.array_equal(got8, ref8), f"seed {seed}: max diff {np.abs(got - ref).max()}"
+    for k in ("segments", "surface_hits", "rng_draws"):
+        assert gc[k] == rc[k], k
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_degenerate_scenes_render_identically_in_the_fast_order(rt, orc, seed):
+    """Exact ties (duplicates, coplanar overlaps), zero and negative radii, zero-area primitives, a sphere around the camera:
+    the re-grouped hierarchy resolves every one of them the way the reference's visiting order does."""
+    scene = random_degenerate_scene(11000 + seed)
+    cam = look_at_camera(rt)
+    ref, ref8, rc = orc.render(scene.desc_ptr, cam, 7, 4)
+    fast = rt.FastOrderScene(scene, cam.center)
+    assert fast.exact
+    got, got8, gc = orc.render(fast.desc_ptr, cam, 7, 4)
+    assert np.array_equal(got, ref) and np.array_equal(got8, ref8), f"seed {seed}: max diff {np.abs(got - ref).max()}"
+    for k in ("segments", "surface_hits", "rng_draws"):
+        assert gc[k] == rc[k], k
 
 
 def test_degenerate_scene_of_coincident_spheres_is_handled(rt, orc):

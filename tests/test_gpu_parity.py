@@ -749,6 +749,46 @@ def test_random_zoo_scenes_on_the_device(rt, orc, renderer, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_random_sphere_scenes_on_the_device(rt, orc, renderer, seed):
+    """Random sphere-only scenes (tests/test_fast_order_random.py::random_sphere_scene: 5-700 spheres, radii over four orders of
+    magnitude, a cluster far from the origin, moving spheres, a glass ball around everything): the headline kernel -- the lean
+    MIXED program with f32 centre / half-extent boxes -- against the oracle, and equal to the reference order double for double."""
+    from tests.test_fast_order_random import look_at_camera, random_sphere_scene
+
+    scene = random_sphere_scene(12100 + seed)
+    cam = look_at_camera(rt)
+    ref, ref8, ocnt = orc.render(scene.desc_ptr, cam, 7, 4)
+    renderer.upload(scene)
+    gpu, gpu8, cnt = renderer.render_host(cam, seed=7, count=True)
+    assert rmse(gpu, ref) < F64_RMSE_BOUND and np.array_equal(gpu8, ref8) and cnt == ocnt
+    info = renderer.upload_fast(scene, cam.center)
+    assert info["exact"] and info["proven"] and "256u" in renderer.kernel_name()
+    fast, fast8, _ = renderer.render_host(cam, seed=7)
+    assert np.array_equal(fast, gpu) and np.array_equal(fast8, gpu8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_random_degenerate_scenes_on_the_device(rt, orc, renderer, seed):
+    """Exact ties (the same primitive twice, coplanar overlaps), radius 0 and below, zero-area primitives, a sphere around the
+    camera (tests/test_fast_order_random.py::random_degenerate_scene): the device resolves them as the reference does, in both
+    orders."""
+    from tests.test_fast_order_random import look_at_camera, random_degenerate_scene
+
+    scene = random_degenerate_scene(11100 + seed)
+    cam = look_at_camera(rt)
+    ref, ref8, ocnt = orc.render(scene.desc_ptr, cam, 7, 4)
+    renderer.upload(scene)
+    gpu, gpu8, cnt = renderer.render_host(cam, seed=7, count=True)
+    assert rmse(gpu, ref) < F64_RMSE_BOUND and np.array_equal(gpu8, ref8) and cnt == ocnt
+    info = renderer.upload_fast(scene, cam.center)
+    assert info["exact"]
+    fast, fast8, _ = renderer.render_host(cam, seed=7)
+    assert np.array_equal(fast, gpu) and np.array_equal(fast8, gpu8)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(3))
 def test_random_big_scenes_on_the_device(rt, orc, renderer, seed):
     """Random scenes of a few thousand primitives (tests/test_fast_order_random.py::random_big_scene): the traversal program is

@@ -1,7 +1,8 @@
 """A larger device-vs-oracle sweep than the test suite affords: random scenes (tests/test_fast_order_random.py's generators:
 soups of spheres / quads / triangles with moving spheres, nested lists and rotate_y / translate instances; fog scenes with
 sphere-bounded media inside one another and around the camera; "zoo" scenes with all seven materials, the five textures, a
-textured medium and point lights; "big" scenes of 1 800 - 4 200 primitives whose traversal program does not fit LDS), each rendered on the device in the reference order and in
+textured medium and point lights; "degenerate" scenes of exact ties, zero radii, zero-area primitives and a sphere around the camera;
+"big" scenes of 1 800 - 4 200 primitives whose traversal program does not fit LDS), each rendered on the device in the reference order and in
 the fast order and compared with the CPU oracle of the same description at the same seed.
 
   python3 tools/fuzz_parity.py [n_per_family=100] [first_seed=50000]
@@ -21,7 +22,7 @@ import torch  # noqa: E402
 
 import raytracingoneweekendapplication_amd as rt  # noqa: E402
 from oracle import orc  # noqa: E402
-from tests.test_fast_order_random import look_at_camera, random_fog_scene, random_big_scene, random_scene, random_zoo_scene  # noqa: E402
+from tests.test_fast_order_random import look_at_camera, random_fog_scene, random_big_scene, random_degenerate_scene, random_scene, random_sphere_scene, random_zoo_scene  # noqa: E402
 
 
 def random_camera(rnd):
@@ -41,7 +42,7 @@ def main():
     renderer = rt.Renderer(0)
     import random
     fixed = look_at_camera(rt)
-    families = (("soup", lambda s: random_scene(s)), ("soup+triangles", lambda s: random_scene(s, triangles=True)), ("fog", random_fog_scene), ("zoo", random_zoo_scene),
+    families = (("spheres only (the lean MIXED kernel)", random_sphere_scene), ("soup", lambda s: random_scene(s)), ("soup+triangles", lambda s: random_scene(s, triangles=True)), ("fog", random_fog_scene), ("zoo", random_zoo_scene), ("degenerate", random_degenerate_scene),
                 ("big (programs larger than LDS)", random_big_scene))
     from raytracingoneweekendapplication_amd import tiling
     dev = torch.device("cuda", 0)

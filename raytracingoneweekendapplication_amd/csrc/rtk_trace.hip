@@ -757,9 +757,10 @@ RTK_DEV float max3_clamp01(float a, float b, float c) { float r; asm("v_max3_f32
 RTK_DEV float min3_clamp01(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 // (Packed f32 arithmetic for this test was measured in round 3 and removed: five v_pk_fma_f32 with op_sel / neg modifiers
 // (inline asm on aligned register pairs: no moves) instead of nine v_fma_f32 -- 12 instead of 16 VALU instructions per box
-// step in the ISA, same bits, same image -- ran C2 at 19.35 instead of 18.50 ms: the packed instruction issues at 0.51 per
-// cycle against 0.68 for v_fma_f32 (csrc/rtk_microbench.hip) and lengthens the step's dependent chain, which is what the
-// step waits for.  Left to the compiler (ext_vector_type(2) fma) the same test cost 9-19 extra moves per step: 22.6 ms.)
+// step in the ISA, same bits, same image -- ran C2 at 19.35 instead of 18.50 ms: the packed instruction issues at 0.24 per
+// cycle per SIMD against 0.45 for v_fma_f32 (csrc/rtk_microbench.hip, aggregate rates: two operations per lane at half the
+// rate -- five packed cost what ten plain ones do) and lengthens the step's dependent chain.  Left to the compiler
+// (ext_vector_type(2) fma) the same test cost 9-19 extra moves per step: 22.6 ms.)
 RTK_DEV bool slab_test32_chs(const MixedHead& b, V3<float> oi, V3<float> inv) {
     const float tcx = __builtin_fmaf(b.f(0), inv.x, -oi.x), tcy = __builtin_fmaf(b.f(1), inv.y, -oi.y), tcz = __builtin_fmaf(b.f(2), inv.z, -oi.z);
     const float ax = __builtin_fabsf(inv.x), ay = __builtin_fabsf(inv.y), az = __builtin_fabsf(inv.z);
@@ -1930,6 +1931,10 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL, IN_LDS>())) void rtk_r
         // The kind with the most ready lanes wins; ties go to the cheaper kind (order of the tests).  Written as
         // nested comparisons on purpose: a running "pick/most" update chain compiled to a 9 % slower kernel
         // (tools/ab/run_ab.sh A/B on the same box: 78.5 ms vs 70.2 ms per C2 frame).
+        // (round 3: a shortcut for the common case -- 32 or more lanes on box records are a majority, so the other five ballots need
+        // not be counted -- left the pick unchanged and the lean kernel with 128 VGPRs + 28 B of scratch instead of 110 + 0
+        // (compile-only, tools/kernel_resources.py): not built.  The vote's cost is the wait for the lanes' record kinds, not its
+        // thirty instructions.)
         int pick;
         if (n_box >= n_sph && n_box >= n_quad && n_box >= n_tri && n_box >= n_shd && n_box >= n_oth) pick = W_BOX;
         else if (n_sph >= n_quad && n_sph >= n_tri && n_sph >= n_shd && n_sph >= n_oth) pick = W_SPHERE;
@@ -2188,6 +2193,9 @@ __global__ __launch_bounds__((max_threads<real, FEAT_ALL, IN_LDS>())) void rtk_r
           }
         } else if (pick == W_SHADE) {
             // 1. the body of ray_color for the lanes whose segment ended; a finished (pixel, chunk) is written out
+            // (round 3, measured and removed: lanes whose closest hit carries a noise or image texture parked without a vote until
+            // 4 - 16 of them had gathered -- C5 34.1 - 34.3 vs 31.9 ms at 32 spp for every threshold: the textures are 9 % of that
+            // frame (tools/knockout.py), the gathering saved none of it and the extra ballot and spills cost 7 %.)
             bool finished = false, next_sample = false, alive = false;
 #if RTK_AB_SHADE_PRIO
             __builtin_amdgcn_s_setprio(RTK_AB_SHADE_PRIO);

@@ -42,6 +42,7 @@
 // the reference's own boxes would have let through because of rounding.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -363,8 +364,19 @@ struct Optimizer {
 
     struct Built {
         int32_t node;
-        double cost;  // expected cost given that the enclosing box was entered
+        double cost;   // expected cost given that the enclosing box was entered
+        double first;  // ... of which this much is paid whatever the ray does next: the first test of every top-level member (one slab
+                       // test for a boxed node, the whole test for a bare primitive) -- what a ray that misses the node still costs
     };
+    // A boxed pair whose box a ray is likely to enter whenever it entered the enclosing one is not worth its slab test: a box() of
+    // six quads, the walls of a room or a leaf of two neighbours span (nearly) the same box at every level of a binary hierarchy.
+    // represent() prices the pair WITHOUT its box as well -- members handed to the enclosing node as a plain list -- and takes
+    // the cheaper form: with the box C + P x inner, without it P x inner + (1 - P) x (first tests of the members); for two
+    // boxed members that is "drop the box when P > 1/2".  RTK_OPT_FLATTEN=0 keeps every box (tools/: A/B).
+    bool flatten = [] {
+        const char* e = std::getenv("RTK_OPT_FLATTEN");
+        return !(e && e[0] == '0');
+    }();
 
     // One side of a split: the cheaper of "test the items one after the other" and "a box, then recurse".
     Built represent(std::vector<Item>& items, size_t begin, size_t end, const Box& parent) {
@@ -378,9 +390,9 @@ struct Optimizer {
                 const Box padded = grown(it.box, margin);
                 out.boxes.push_back(rtk_aabb{padded.lo[0], padded.hi[0], padded.lo[1], padded.hi[1], padded.lo[2], padded.hi[2]});
                 const int32_t nothing = push_node(RTK_NODE_LIST, int32_t(out.children.size()), 0, 0);
-                return Built{push_node(RTK_NODE_BVH, it.node, nothing, int32_t(out.boxes.size()) - 1), boxed};
+                return Built{push_node(RTK_NODE_BVH, it.node, nothing, int32_t(out.boxes.size()) - 1), boxed, kBoxCost};
             }
-            return Built{it.node, it.cost};
+            return Built{it.node, it.cost, it.cost};
         }
         double linear = 0;
         Box b = Box::empty();
@@ -389,18 +401,32 @@ struct Optimizer {
             b.grow(items[k].box);
         }
         const size_t nodes_mark = out.nodes.size(), child_mark = out.children.size(), box_mark = out.boxes.size();
-        Built inner = split(items, begin, end, b);
+        Built l{-1, 0, 0}, r{-1, 0, 0};
+        Built inner = split(items, begin, end, b, &l, &r);
         const double pa = parent.area();
-        const double boxed = kBoxCost + (pa > 0 ? std::min(1.0, b.area() / pa) : 1.0) * inner.cost;
-        if (int(end - begin) <= opts.max_leaf && linear <= boxed) {
+        const double pb = pa > 0 ? std::min(1.0, b.area() / pa) : 1.0;
+        const double boxed = kBoxCost + pb * inner.cost;
+        const double bare = flatten ? pb * inner.cost + (1.0 - pb) * (l.first + r.first) : std::numeric_limits<double>::infinity();
+        if (int(end - begin) <= opts.max_leaf && linear <= boxed && linear <= bare) {
             out.nodes.resize(nodes_mark);  // discard the subtree just built (primitive nodes were created earlier)
             out.children.resize(child_mark);
             out.boxes.resize(box_mark);
             // nearest first inside a leaf as well
             order_items(items, begin, end);
-            return Built{emit_list(items, begin, end), linear};
+            return Built{emit_list(items, begin, end), linear, linear};
         }
-        return Built{inner.node, boxed};
+        if (bare < boxed && inner.node == int32_t(out.nodes.size()) - 1 && out.nodes.back().kind == RTK_NODE_BVH &&
+            out.nodes.back().c == int32_t(out.boxes.size()) - 1) {
+            // the pair's own node and box were pushed last: drop them, hand its two members (in their visiting order) to the caller
+            const int32_t first_member = out.nodes.back().a, second_member = out.nodes.back().b;
+            out.nodes.pop_back();
+            out.boxes.pop_back();
+            const int32_t at = int32_t(out.children.size());
+            out.children.push_back(first_member);
+            out.children.push_back(second_member);
+            return Built{push_node(RTK_NODE_LIST, at, 2, 0), bare, l.first + r.first};
+        }
+        return Built{inner.node, boxed, kBoxCost};
     }
 
     void order_items(std::vector<Item>& items, size_t begin, size_t end) {
@@ -415,7 +441,7 @@ struct Optimizer {
     }
 
     // A BVH node over items[begin, end) (>= 2 items) whose box is `b`: full-sweep SAH on the three axes.
-    Built split(std::vector<Item>& items, size_t begin, size_t end, const Box& b) {
+    Built split(std::vector<Item>& items, size_t begin, size_t end, const Box& b, Built* left_out = nullptr, Built* right_out = nullptr) {
         const size_t n = end - begin;
         int best_axis = -1;
         size_t best_k = 0;
@@ -480,7 +506,9 @@ struct Optimizer {
         const Box padded = grown(b, margin);
         out.boxes.push_back(rtk_aabb{padded.lo[0], padded.hi[0], padded.lo[1], padded.hi[1], padded.lo[2], padded.hi[2]});
         const int32_t node = push_node(RTK_NODE_BVH, l.node, r.node, int32_t(out.boxes.size()) - 1);
-        return Built{node, l.cost + r.cost};
+        if (left_out) *left_out = l;
+        if (right_out) *right_out = r;
+        return Built{node, l.cost + r.cost, l.first + r.first};
     }
 
     int32_t build_group(int32_t node, Box& box, double& cost, int depth) {
@@ -750,7 +778,19 @@ static int optimize_once(const rtk_scene_desc* scene, const rtk_optimize_opts* o
         const rtk_aabb& rb = h->boxes[size_t(rn.c)];
         const bool inside = opts.eye.x > rb.xmin && opts.eye.x < rb.xmax && opts.eye.y > rb.ymin && opts.eye.y < rb.ymax && opts.eye.z > rb.zmin &&
                             opts.eye.z < rb.zmax;
-        if (inside) {
+        // ... and from an eye outside it, only primary rays can miss the root box -- one segment in (paths' length) -- and few of them
+        // when the box fills the view: the test is dropped as well while the eye is nearer to the box than the box is wide (the
+        // Cornell box seen through its open side: one slab test less for every segment, a tenth of that scene's).  A ray
+        // that does miss then pays for the root's members' own boxes instead -- cost, never correctness.
+        const double lo[3] = {rb.xmin, rb.ymin, rb.zmin}, hi[3] = {rb.xmax, rb.ymax, rb.zmax}, e[3] = {opts.eye.x, opts.eye.y, opts.eye.z};
+        double dist2 = 0, diag2 = 0;
+        for (int a = 0; a < 3; a++) {
+            const double d = e[a] < lo[a] ? lo[a] - e[a] : (e[a] > hi[a] ? e[a] - hi[a] : 0.0);
+            dist2 += d * d;
+            diag2 += (hi[a] - lo[a]) * (hi[a] - lo[a]);
+        }
+        const bool near_by = op.flatten && dist2 < diag2;
+        if (inside || near_by) {
             const int32_t first = int32_t(h->children.size());
             h->children.push_back(rn.a);
             h->children.push_back(rn.b);

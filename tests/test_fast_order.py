@@ -116,6 +116,28 @@ def test_fast_order_cuts_the_slab_tests_of_the_benchmark_scenes(rt, orc):
         assert prim(b) <= prim(a)
 
 
+def test_boxes_that_are_entered_anyway_are_dropped(rt, orc, monkeypatch):
+    """A boxed pair whose box a ray enters whenever it entered the enclosing one is not worth its slab test (a box() of six
+    quads, the walls of a room: every level of a binary hierarchy over them spans the same box).  The optimiser prices each
+    pair with and without its box (rtk_optimize.cpp, `Built::first`) and hands the members of the cheaper form to the enclosing
+    node: the same image bit for bit, a third fewer slab tests in the Cornell box, never more primitive tests than a tenth
+    above.  RTK_OPT_FLATTEN=0 (tools/) keeps every box."""
+    for name, w, h, spp, at_most in (("cornell_box", 60, 60, 4, 0.75), ("book2_final", 96, 54, 2, 0.99), ("mesh", 96, 54, 2, 0.99), ("book1_final", 96, 54, 2, 1.0)):
+        scene = build(rt, name)
+        cam = scene.camera(w, h, spp, 0)
+        monkeypatch.setenv("RTK_OPT_FLATTEN", "0")
+        every_box = scene.fast_order(cam.center)
+        monkeypatch.delenv("RTK_OPT_FLATTEN")
+        fast = scene.fast_order(cam.center)
+        assert fast.info["n_bvh_nodes_out"] < every_box.info["n_bvh_nodes_out"]
+        img_a, _, a = orc.render(every_box.desc_ptr, cam, RENDER_SEED, 4)
+        img_b, _, b = orc.render(fast.desc_ptr, cam, RENDER_SEED, 4)
+        assert np.array_equal(img_a, img_b) and a["rng_draws"] == b["rng_draws"]
+        assert b["box_tests"] <= at_most * a["box_tests"], (name, a["box_tests"], b["box_tests"])
+        prim = lambda c: c["sphere_tests"] + c["quad_tests"] + c["triangle_tests"]
+        assert prim(b) <= 1.1 * prim(a), (name, prim(a), prim(b))
+
+
 def test_fast_order_is_deterministic_and_eye_is_optional(rt, orc):
     scene = build(rt, "book1_final")
     cam = scene.camera(48, 27, 2, 50)

@@ -1203,6 +1203,21 @@ static int compile_scene(const rtk_scene_desc* scene, Program& prog) {
     comp.emit(scene->root, Chain{}, false, 0);
     if (prog.error_code != RTK_OK) return fail(prog.error_code, "rtk_scene_upload: %s", prog.error.c_str());
     if (prog.n_primitive_ops == 0) return fail(RTK_ERR_INVALID, "rtk_scene_upload: no primitive reachable from the root");
+    // A switch back to world space that is the program's last record serves nobody: what follows is OP_END, the shade step works
+    // from the world ray and the hit record's own chain, and begin_segment sets the object ray anew.  It is a scheduler step of
+    // its own for every ray that entered the last instance (the Cornell box: a fifth of its chain steps), so it is dropped and
+    // the skip links that pointed behind it are moved up.  (RTK_KEEP_LAST_CHAIN=1 keeps it: tools/, A/B.)
+    if (prog.ops.size() > 1 && (prog.ops.back().kind_payload & 15u) == OP_CHAIN && (prog.ops.back().kind_payload >> 4) == 0u && prog.ops.back().aux == 0u &&
+        !getenv("RTK_KEEP_LAST_CHAIN")) {
+        const uint32_t behind = uint32_t(prog.ops.size());
+        prog.ops.pop_back();
+        prog.ranks.pop_back();
+        prog.extra.pop_back();
+        for (Op& op : prog.ops) {
+            const uint32_t kind = op.kind_payload & 15u;
+            if ((kind == OP_BOX || kind == OP_MED_MID) && op.aux == behind) op.aux = behind - 1;
+        }
+    }
     prog.ops.push_back(Op{make_op(OP_END, 0), 0});
     prog.ranks.push_back(0);
     prog.extra.push_back(0);

@@ -202,12 +202,16 @@ RTK_DEV V3<real> random_unit_vector(uint32_t& s, Counters<COUNT>& cnt) {
 #define RTK_CHAIN_PREFETCH 1
 #endif
 template <uint32_t FEAT>
-constexpr bool kChainPrefetch = (FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_LDS_BOXES)) == kFeatAll;
+constexpr bool kChainPrefetch = (FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_LDS_BOXES)) == kFeatAll || (FEAT & ~uint32_t(F_FMA_BOX | F_F32_BOX | F_MATTE)) == kFeatQuadBox;
 // The constants of the first two steps of a chain are requested together, in front of the branches that pick them: walking
 // the record step by step costs a dependent read per branch (count, is_rotate[k], that step's constants), and a chain
 // switch is nothing but those reads and two dozen operations.  Longer chains (kMaxChain = 4) finish in the loop.
-// PREFETCH is for the full-feature kernels (C5 44.4 -> 43.6 ms); the quad/box kernels at 128 VGPRs would spill for it
-// (scratch 16 -> 60 B, C3 26.2 -> 26.5 ms).
+// PREFETCH: the full-feature kernels (C5 44.4 -> 43.6 ms) and, since round 3, the quad/box kernels: with the deep hierarchy of
+// round 2 the 36 B of scratch it costs them outweighed it (C3 26.2 -> 26.5 ms at 100 spp); on the flattened programs a chain
+// switch is a larger share of the frame and it pays (21.70 -> 21.25 ms).  (Reading the staged chains through a pointer typed
+// as LDS -- ds_read instead of the flat loads a generic pointer compiles to, 3.6 per Cornell sample -- was measured in round 3
+// as well: 21.51 without the prefetch, 21.70 with it, C5 29.46 -> 29.80 ms: the register allocator's answer costs more than
+// the cheaper loads save; removed.)
 template <bool PREFETCH = false, typename real>
 RTK_DEV void apply_chain(const ChainRec<real>* __restrict__ chains, uint32_t chain, V3<real> wo, V3<real> wd, V3<real>& o, V3<real>& d) {
     o = wo;

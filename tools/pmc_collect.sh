@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/pmc_${round}_${cfg}
 rm -rf "$out"; mkdir -p "$out" profiles
 python3 -c "import bench; print(bench.kernel_source_hash())" > "$out/source_hash.txt"   # the sources the profiled library was built from
-BENCH="bench.py --gpus 1 --config $cfg --steps $steps --warmup 1 --no-cpu-baseline --no-f32 --no-other-order --no-other-configs"
+BENCH="bench.py --gpus 1 --config $cfg --steps $steps --warmup 1 --no-cpu-baseline --no-f32 --no-other-order --no-other-configs --no-microbench"
 pass() { name=$1; shift; echo "pass $name ($cfg)"; rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 $BENCH > "$out/$name.log" 2>&1 || echo "pass $name failed"; }
 pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA
 pass sq2 SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVES
